@@ -1,0 +1,30 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (its directory name has a hyphen, so it is imported by string)."""
+    return importlib.import_module("image-super-resolution_amd")
+
+
+def load_golden(name):
+    import torch
+    d = torch.load(os.path.join(GOLDEN, name), weights_only=True)
+    if "sd" in d:
+        d["sd"] = {k: (v.float() if v.is_floating_point() else v) for k, v in d["sd"].items()}
+    return d

@@ -1,0 +1,89 @@
+"""CPU: the oracle restatement reproduces the golden vectors captured from the reference
+(oracle/make_golden.py ran the reference's own modules from /root/reference).  Tolerances are fp32
+round-off only (the restatement uses the same torch ops)."""
+import torch
+from conftest import load_golden
+from ffsr_oracle import drct, grl, nafnet, mambair, fusion, pipeline
+
+TOL = 5e-6
+
+
+def _close(a, b, tol=TOL):
+    assert a.shape == b.shape
+    assert (a - b).abs().max().item() <= tol
+
+
+def test_nafnet_small():
+    g = load_golden("nafnet_small.pt")
+    sr, feat = nafnet.nafnet_sr(g["sd"], g["lr"], **g["cfg"])
+    _close(sr, g["sr"]); _close(feat, g["feat"])
+
+
+def test_drct_small():
+    g = load_golden("drct_small.pt")
+    sr, feat = drct.drct_forward(g["sd"], g["lr"])
+    _close(sr, g["sr"]); _close(feat, g["feat"])
+
+
+def test_grl_small():
+    g = load_golden("grl_small.pt")
+    sr, feat = grl.grl_forward(g["sd"], g["lr"])
+    _close(sr, g["sr"]); _close(feat, g["feat"])
+
+
+def test_mambair_small():
+    # the scan inside is oracle/ffsr_oracle/scan.py on BOTH sides (mamba-ssm is absent): this pins
+    # everything around the scan; the scan arithmetic itself is "parity unpinned".
+    g = load_golden("mambair_small.pt")
+    sr, feat = mambair.mambair_forward(g["sd"], g["lr"])
+    _close(sr, g["sr"]); _close(feat, g["feat"], 2e-5)
+
+
+def test_fusion_full_both_sizes():
+    g = load_golden("fusion_full.pt")
+    for tag, c in g["cases"].items():
+        imgs = {k: v.float() for k, v in c["imgs"].items()}
+        feats = {k: v.float() for k, v in c["feats"].items()}
+        _close(fusion.fusion_forward(g["sd"], c["lr"], imgs, feats), c["out"])
+        for a, b in zip(fusion.frequency_bands(g["sd"], c["lr"]), c["bands"]):
+            _close(a, b)
+
+
+def test_host_logic_40x56():
+    h = load_golden("host_40x56.pt")
+    w = {n: load_golden(f"{f}_small.pt")["sd"] for n, f in
+         (("drct", "drct"), ("grl", "grl"), ("nafnet", "nafnet"), ("mamba", "mambair"))}
+    lr = pipeline.uint2tensor4(h["img"].numpy())
+    lp, (hh, ww) = pipeline.pad16(lr)
+    assert (hh, ww) == (40, 56) and lp.shape[-2:] == (48, 64)
+    _close(lp, h["lr_padded"], 0.0)
+    imgs, feats, lr_in = pipeline.run_experts(w, lr, naf_cfg=load_golden("nafnet_small.pt")["cfg"])
+    for n, key in (("drct", "drct"), ("grl", "grl"), ("nafnet", "naf"), ("mamba", "mamba")):
+        _close(imgs[n], h[f"{key}_sr"].float(), 1e-3)      # fixture stored as fp16
+        _close(feats[n], h[f"{key}_feat"].float(), 4e-3)
+
+
+def test_uint8_rounding_is_half_to_even():
+    t = torch.tensor([[[[0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 1.2, -0.3]]]]).repeat(1, 3, 1, 1)
+    u = pipeline.tensor2uint(t)
+    assert u.shape == (1, 6, 3) and u[0, :, 0].tolist() == [0, 2, 2, 254, 255, 0]
+
+
+def test_scan_matches_naive_loop():
+    from ffsr_oracle.scan import selective_scan_ref
+    g = torch.Generator().manual_seed(0)
+    B, Dm, N, L, G = 1, 8, 4, 37, 2
+    u, dt = torch.randn(B, Dm, L, generator=g), torch.randn(B, Dm, L, generator=g)
+    A = -torch.rand(Dm, N, generator=g) - 0.1
+    Bm, Cm = torch.randn(B, G, N, L, generator=g), torch.randn(B, G, N, L, generator=g)
+    D, bias = torch.randn(Dm, generator=g), torch.randn(Dm, generator=g)
+    y = selective_scan_ref(u, dt, A, Bm, Cm, D, delta_bias=bias, delta_softplus=True)
+    ref = torch.zeros_like(y)
+    for d in range(Dm):
+        h = torch.zeros(N, dtype=torch.float64)
+        for t in range(L):
+            x = float(dt[0, d, t] + bias[d])
+            delta = x if x > 20 else float(torch.log1p(torch.exp(torch.tensor(x, dtype=torch.float64))))
+            h = torch.exp(delta * A[d].double()) * h + delta * Bm[0, d // (Dm // G), :, t].double() * float(u[0, d, t])
+            ref[0, d, t] = float((h * Cm[0, d // (Dm // G), :, t].double()).sum()) + float(D[d] * u[0, d, t])
+    assert (y - ref).abs().max() < 1e-4
