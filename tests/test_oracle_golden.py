@@ -64,9 +64,9 @@ def test_host_logic_40x56():
 
 
 def test_uint8_rounding_is_half_to_even():
-    t = torch.tensor([[[[0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 1.2, -0.3]]]]).repeat(1, 3, 1, 1)
+    t = torch.tensor([[[[0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 1.2, -0.3]]]]).repeat(1, 3, 2, 1)
     u = pipeline.tensor2uint(t)
-    assert u.shape == (1, 6, 3) and u[0, :, 0].tolist() == [0, 2, 2, 254, 255, 0]
+    assert u.shape == (2, 6, 3) and u[1, :, 2].tolist() == [0, 2, 2, 254, 255, 0]
 
 
 def test_scan_matches_naive_loop():
