@@ -1,0 +1,505 @@
+// Window attention kernels (gfx950).
+//
+// (1) ffsr_window_attn_f32  -- DRCT's (shifted) 16x16 window MSA, fp32 MFMA 32x32x2, fused
+//     QK^T*scale + relative-position bias (+ shift mask computed from region ids) -> softmax -> PV.
+//     The cyclic roll, window partition / reverse of the reference are folded into the token addressing.
+// (2) ffsr_grl_window_attn_f32 / ffsr_grl_stripe_attn_f32 -- GRL's 8x8 cosine window attention and the two-hop
+//     anchored stripe attention.  64 tokens x head_dim 30: one wave per (window, head) on the VALU.
+// (3) ffsr_pixel_mha_f32 -- the fusion net's per-pixel multi-head attention across 9 bands / 4 experts (K11).
+#include "ffsr_common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------------------------
+// (1) DRCT window attention.  grid = (N/64 query blocks, heads, windows*B), 256 threads.
+// qkv: [B*H*W, ldq] with q at col h*hd, k at C + h*hd, v at 2C + h*hd.  bias: [heads, N, N] dense.
+// --------------------------------------------------------------------------------------------------------------
+struct WinArgs {
+  const float* qkv;
+  const float* bias;
+  float* out;
+  int ldq, ldo, C, H, W, ws, shift, heads, hd, hdp, masked;
+  float scale;
+};
+
+__device__ __forceinline__ int region_id(int p, int n, int ws, int shift) {
+  // python slices [0,-ws), [-ws,-shift), [-shift, end) on an axis of length n
+  return p < n - ws ? 0 : (p < n - shift ? 1 : 2);
+}
+
+template <int DT>  // DT = number of 32-wide head_dim tiles (hd <= 32*DT)
+__global__ __launch_bounds__(256) void window_attn_kernel(WinArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int N = p.ws * p.ws;          // tokens per window (multiple of 64)
+  const int QS = p.hdp + 4;           // row stride of Q / KV tiles (floats); (hdp+4)/4 is odd
+  const int SS = N + 4;               // row stride of S
+  float* Qs = lds;                    // [64][QS]
+  float* KVs = Qs + 64 * QS;          // [64][QS]
+  float* Ss = KVs + 64 * QS;          // [64][SS]
+  int* tok_pix = reinterpret_cast<int*>(Ss + 64 * SS);  // [N] source pixel of every token of the window
+  int* tok_reg = tok_pix + N;                           // [N] mask region id
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qb = blockIdx.x, head = blockIdx.y;
+  const int nwx = p.W / p.ws, nwy = p.H / p.ws;
+  const int win = blockIdx.z % (nwx * nwy), b = blockIdx.z / (nwx * nwy);
+  const int wy = win / nwx, wx = win % nwx;
+
+  for (int t = tid; t < N; t += 256) {
+    int py = t / p.ws, px = t % p.ws;
+    int ys = wy * p.ws + py, xs = wx * p.ws + px;  // position in the rolled image
+    int y = ys + p.shift, x = xs + p.shift;
+    if (y >= p.H) y -= p.H;
+    if (x >= p.W) x -= p.W;
+    tok_pix[t] = (b * p.H + y) * p.W + x;
+    tok_reg[t] = p.masked ? region_id(ys, p.H, p.ws, p.shift) * 3 + region_id(xs, p.W, p.ws, p.shift) : 0;
+  }
+  __syncthreads();
+
+  const int hd = p.hd, hdp = p.hdp;
+  // ---- Q block (scaled), zero padded to hdp
+  for (int i = tid; i < 64 * hdp; i += 256) {
+    int r = i / hdp, d = i - r * hdp;
+    float v = 0.f;
+    if (d < hd) v = p.qkv[(size_t)tok_pix[qb * 64 + r] * p.ldq + head * hd + d] * p.scale;
+    Qs[r * QS + d] = v;
+  }
+
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int trow = (wave >> 1) * 32, tcol = (wave & 1) * 32;  // this wave's 32x32 tile of the 64x64 S block
+  // ---- S = Q K^T, one 64-key tile at a time
+  for (int kt = 0; kt < N / 64; ++kt) {
+    __syncthreads();  // previous tile consumed (and Q written, first iteration)
+    for (int i = tid; i < 64 * hdp; i += 256) {
+      int r = i / hdp, d = i - r * hdp;
+      float v = 0.f;
+      if (d < hd) v = p.qkv[(size_t)tok_pix[kt * 64 + r] * p.ldq + p.C + head * hd + d];
+      KVs[r * QS + d] = v;
+    }
+    __syncthreads();
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k8 = 0; k8 < hdp; k8 += 8) {
+      floatx4 a = *reinterpret_cast<const floatx4*>(Qs + (trow + r32) * QS + k8 + 4 * hh);
+      floatx4 bb = *reinterpret_cast<const floatx4*>(KVs + (tcol + r32) * QS + k8 + 4 * hh);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bb[s], acc, 0, 0, 0);
+    }
+    // + bias (+ mask) -> S
+    const int key = kt * 64 + tcol + r32;
+    const int kreg = tok_reg[key];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int qr = trow + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      int q = qb * 64 + qr;
+      float v = acc[e] + p.bias[((size_t)head * N + q) * N + key];
+      if (p.masked && tok_reg[q] != kreg) v += -100.0f;
+      Ss[qr * SS + key] = v;
+    }
+  }
+  __syncthreads();
+  // ---- row softmax: wave handles 16 rows, lane holds N/64 columns
+  for (int rr = 0; rr < 16; ++rr) {
+    float* row = Ss + (wave * 16 + rr) * SS;
+    float v[4];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = lane + 64 * i;
+      v[i] = c < N ? row[c] : -3.0e38f;
+      m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = (lane + 64 * i < N) ? expf(v[i] - m) : 0.f;
+      s += v[i];
+    }
+    s = 1.0f / wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < N) row[lane + 64 * i] = v[i] * s;
+  }
+  // ---- O = P V : 2 row tiles x DT column tiles over 4 waves
+  constexpr int NT = (DT + 1) / 2;  // column tiles per wave
+  floatx16 o[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  const int orow = (wave & 1) * 32;
+  for (int kt = 0; kt < N / 64; ++kt) {
+    __syncthreads();
+    for (int i = tid; i < 64 * hdp; i += 256) {
+      int r = i / hdp, d = i - r * hdp;
+      float v = 0.f;
+      if (d < hd) v = p.qkv[(size_t)tok_pix[kt * 64 + r] * p.ldq + 2 * p.C + head * hd + d];
+      KVs[r * QS + d] = v;
+    }
+    // columns hdp .. 32*DT of the V tile are never read with d >= hdp unguarded (see below)
+    __syncthreads();
+    for (int k8 = 0; k8 < 64; k8 += 8) {
+      floatx4 a = *reinterpret_cast<const floatx4*>(Ss + (orow + r32) * SS + kt * 64 + k8 + 4 * hh);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int ct = (wave >> 1) + 2 * i;
+        if (ct < DT) {
+          const int d = ct * 32 + r32;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            float bv = d < hdp ? KVs[(k8 + 4 * hh + s) * QS + d] : 0.f;
+            o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, o[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- store: col = d on the lane, rows = queries
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int ct = (wave >> 1) + 2 * i;
+    const int d = ct * 32 + r32;
+    if (ct < DT && d < hd) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int qr = orow + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        p.out[(size_t)tok_pix[qb * 64 + qr] * p.ldo + head * hd + d] = o[i][e];
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// (2) GRL attention: one wave per (window, head).  Tokens of an 8x8 window; lane = query token.
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float inv_norm(const float* v, int n) {
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s = fmaf(v[i], v[i], s);
+  return 1.0f / fmaxf(sqrtf(s), 1e-12f);  // F.normalize eps
+}
+
+// qkv: [P, ldq]; this branch's q/k/v start at column col0 with layout [3][heads][HD]; out: [P, ldo] at ocol0 + h*HD
+// biasT: [heads][64 keys][64 queries]; logit: [heads] already exp(min(logit_scale, ln 100))
+template <int HD>
+__global__ __launch_bounds__(64) void grl_window_kernel(const float* __restrict__ qkv, int ldq, int col0,
+                                                        const float* __restrict__ biasT, const float* __restrict__ logit,
+                                                        float* __restrict__ out, int ldo, int ocol0, int H, int W, int heads,
+                                                        int shift) {
+  constexpr int WS = 8, N = 64;
+  __shared__ __attribute__((aligned(16))) float Ks[N][HD + 2];
+  __shared__ __attribute__((aligned(16))) float Vs[N][HD + 2];
+  __shared__ int regs[N];
+  const int lane = threadIdx.x;
+  const int head = blockIdx.y;
+  const int nwx = W / WS, nwy = H / WS;
+  const int win = blockIdx.x % (nwx * nwy), b = blockIdx.x / (nwx * nwy);
+  const int wy = win / nwx, wx = win % nwx;
+  const int ys = wy * WS + lane / WS, xs = wx * WS + lane % WS;
+  int y = ys + shift, x = xs + shift;
+  if (y >= H) y -= H;
+  if (x >= W) x -= W;
+  const size_t pix = ((size_t)b * H + y) * W + x;
+  const float* row = qkv + pix * ldq + col0 + head * HD;
+  float q[HD], k[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] = row[d];
+    k[d] = row[heads * HD + d];
+    Vs[lane][d] = row[2 * heads * HD + d];
+  }
+  const float qn = inv_norm(q, HD) * logit[head], kn = inv_norm(k, HD);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] *= qn;
+    Ks[lane][d] = k[d] * kn;
+  }
+  const int myreg = shift ? region_id(ys, H, WS, shift) * 3 + region_id(xs, W, WS, shift) : 0;
+  regs[lane] = myreg;
+  __syncthreads();
+  float s[N];
+  float m = -3.0e38f;
+  const float* bt = biasT + (size_t)head * N * N + lane;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) a = fmaf(q[d], Ks[j][d], a);
+    a += bt[j * N];
+    if (shift && regs[j] != myreg) a += -100.0f;
+    s[j] = a;
+    m = fmaxf(m, a);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    s[j] = expf(s[j] - m);
+    sum += s[j];
+  }
+  const float inv = 1.0f / sum;
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float pj = s[j] * inv;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = fmaf(pj, Vs[j][d], o[d]);
+  }
+  float* orow = out + pix * ldo + ocol0 + head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) orow[d] = o[d];
+}
+
+// anchors: [B, H/2, W/2, lda] with head h at column h*HD.  bias1T: [heads][64 keys][16 anchors] (anchor <- window),
+// bias2T: [heads][16 anchors][64 queries] (window <- anchor).  No stripe shift in GRL-B (grl/__init__.py:139).
+template <int HD>
+__global__ __launch_bounds__(64) void grl_stripe_kernel(const float* __restrict__ qkv, int ldq, int col0,
+                                                        const float* __restrict__ anchor, int lda,
+                                                        const float* __restrict__ bias1T, const float* __restrict__ bias2T,
+                                                        const float* __restrict__ logit1, const float* __restrict__ logit2,
+                                                        float* __restrict__ out, int ldo, int ocol0, int H, int W, int heads) {
+  constexpr int WS = 8, N = 64, AW = 4, NA = 16;
+  __shared__ __attribute__((aligned(16))) float Ks[N][HD + 2];
+  __shared__ __attribute__((aligned(16))) float Vs[N][HD + 2];
+  __shared__ __attribute__((aligned(16))) float As[NA][HD + 2];   // normalised anchors
+  __shared__ __attribute__((aligned(16))) float Gs[NA][HD + 2];   // anchors' gathered values
+  __shared__ float P1[NA][N + 1];
+  const int lane = threadIdx.x;
+  const int head = blockIdx.y;
+  const int nwx = W / WS, nwy = H / WS;
+  const int win = blockIdx.x % (nwx * nwy), b = blockIdx.x / (nwx * nwy);
+  const int wy = win / nwx, wx = win % nwx;
+  const int y = wy * WS + lane / WS, x = wx * WS + lane % WS;
+  const size_t pix = ((size_t)b * H + y) * W + x;
+  const float* row = qkv + pix * ldq + col0 + head * HD;
+  float q[HD], k[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] = row[d];
+    k[d] = row[heads * HD + d];
+    Vs[lane][d] = row[2 * heads * HD + d];
+  }
+  const float kn = inv_norm(k, HD);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) Ks[lane][d] = k[d] * kn;
+  if (lane < NA) {
+    const int ay = wy * AW + lane / AW, ax = wx * AW + lane % AW;
+    const float* ar = anchor + (((size_t)b * (H / 2) + ay) * (W / 2) + ax) * lda + head * HD;
+    float a[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) a[d] = ar[d];
+    const float an = inv_norm(a, HD);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) As[lane][d] = a[d] * an;
+  }
+  __syncthreads();
+  // ---- hop 1: anchors attend to the stripe's tokens. lane = (anchor a, key quarter kq)
+  {
+    const int a = lane & 15, kq = lane >> 4;
+    const float l1 = logit1[head];
+    float s[16];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = kq * 16 + jj;
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc = fmaf(As[a][d], Ks[j][d], acc);
+      acc = acc * l1 + bias1T[((size_t)head * N + j) * NA + a];
+      s[jj] = acc;
+      m = fmaxf(m, acc);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      s[jj] = expf(s[jj] - m);
+      sum += s[jj];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) P1[a][kq * 16 + jj] = s[jj] * inv;
+  }
+  __syncthreads();
+  // G[a][d] = sum_j P1[a][j] V[j][d]   (16*HD outputs over 64 lanes)
+  for (int i = lane; i < NA * HD; i += 64) {
+    const int a = i / HD, d = i - a * HD;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc = fmaf(P1[a][j], Vs[j][d], acc);
+    Gs[a][d] = acc;
+  }
+  __syncthreads();
+  // ---- hop 2: tokens attend to the anchors. lane = query token
+  const float qn = inv_norm(q, HD) * logit2[head];
+  float s2[NA];
+  float m2 = -3.0e38f;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], As[a][d], acc);
+    acc = acc * qn + bias2T[((size_t)head * NA + a) * N + lane];
+    s2[a] = acc;
+    m2 = fmaxf(m2, acc);
+  }
+  float sum2 = 0.f;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    s2[a] = expf(s2[a] - m2);
+    sum2 += s2[a];
+  }
+  const float inv2 = 1.0f / sum2;
+  float* orow = out + pix * ldo + ocol0 + head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc = fmaf(s2[a], Gs[a][d], acc);
+    orow[d] = acc * inv2;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// (3) per-pixel MHA: qkv [S*T, 3E] (q | k | v, heads of 16) -> out [S*T, E].  thread = (sequence, token, head)
+// --------------------------------------------------------------------------------------------------------------
+template <int T>
+__global__ void pixel_mha_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo, long long S,
+                                 int E, int heads) {
+  constexpr int HD = 16;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= S * T * heads) return;
+  const int h = (int)(idx % heads);
+  const long long st = idx / heads;  // sequence*T + token
+  const long long seq = st / T;
+  const float* qrow = qkv + st * ldq + h * HD;
+  float q[HD];
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    floatx4 v = *reinterpret_cast<const floatx4*>(qrow + d);
+    q[d] = v[0] * 0.25f; q[d + 1] = v[1] * 0.25f; q[d + 2] = v[2] * 0.25f; q[d + 3] = v[3] * 0.25f;  // 1/sqrt(16)
+  }
+  float s[T];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const float* krow = qkv + (seq * T + j) * ldq + E + h * HD;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      floatx4 v = *reinterpret_cast<const floatx4*>(krow + d);
+      acc = fmaf(q[d], v[0], acc); acc = fmaf(q[d + 1], v[1], acc);
+      acc = fmaf(q[d + 2], v[2], acc); acc = fmaf(q[d + 3], v[3], acc);
+    }
+    s[j] = acc;
+    m = fmaxf(m, acc);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    s[j] = expf(s[j] - m);
+    sum += s[j];
+  }
+  const float inv = 1.0f / sum;
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const float* vrow = qkv + (seq * T + j) * ldq + 2 * E + h * HD;
+    const float pj = s[j] * inv;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      floatx4 v = *reinterpret_cast<const floatx4*>(vrow + d);
+      o[d] = fmaf(pj, v[0], o[d]); o[d + 1] = fmaf(pj, v[1], o[d + 1]);
+      o[d + 2] = fmaf(pj, v[2], o[d + 2]); o[d + 3] = fmaf(pj, v[3], o[d + 3]);
+    }
+  }
+  float* orow = out + st * ldo + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    floatx4 v = {o[d], o[d + 1], o[d + 2], o[d + 3]};
+    *reinterpret_cast<floatx4*>(orow + d) = v;
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* out, int ldo, int B, int H, int W,
+                                    int C, int heads, int ws, int shift, float scale, void* stream) {
+  FFSR_CHECK(qkv && bias && out && B > 0 && heads > 0 && C % heads == 0);
+  FFSR_CHECK(ws > 0 && H % ws == 0 && W % ws == 0 && (ws * ws) % 64 == 0 && ws * ws <= 256);
+  FFSR_CHECK(shift >= 0 && shift < ws && ldq >= 3 * C && ldo >= C);
+  const int hd = C / heads;
+  FFSR_CHECK(hd <= 128);
+  WinArgs a;
+  a.qkv = qkv; a.bias = bias; a.out = out; a.ldq = ldq; a.ldo = ldo; a.C = C; a.H = H; a.W = W; a.ws = ws;
+  a.shift = shift; a.heads = heads; a.hd = hd; a.hdp = (hd + 7) / 8 * 8; a.masked = shift > 0; a.scale = scale;
+  const int N = ws * ws;
+  const size_t lds = (size_t)(2 * 64 * (a.hdp + 4) + 64 * (N + 4)) * 4 + 2 * N * 4;
+  FFSR_CHECK(lds <= 160 * 1024);
+  dim3 grid(N / 64, heads, (H / ws) * (W / ws) * B);
+  FFSR_CHECK(grid.z <= 65535);
+  const int DT = (hd + 31) / 32;
+#define LAUNCH_WIN(D)                                                                                            \
+  {                                                                                                              \
+    if (lds > 64 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute((const void*)window_attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                       \
+    hipLaunchKernelGGL(window_attn_kernel<D>, grid, dim3(256), lds, ST, a);                                      \
+  }
+  switch (DT) {
+    case 1: LAUNCH_WIN(1); break;
+    case 2: LAUNCH_WIN(2); break;
+    case 3: LAUNCH_WIN(3); break;
+    default: LAUNCH_WIN(4); break;
+  }
+#undef LAUNCH_WIN
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_grl_window_attn_f32(const float* qkv, int ldq, int col0, const float* biasT, const float* logit,
+                                        float* out, int ldo, int ocol0, int B, int H, int W, int heads, int hd, int shift,
+                                        void* stream) {
+  FFSR_CHECK(qkv && biasT && logit && out && B > 0 && H % 8 == 0 && W % 8 == 0 && heads > 0 && shift >= 0 && shift < 8);
+  dim3 grid((H / 8) * (W / 8) * B, heads);
+  switch (hd) {
+    case 30: hipLaunchKernelGGL(grl_window_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
+    case 10: hipLaunchKernelGGL(grl_window_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
+    default: return FFSR_EINVAL;
+  }
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, const float* anchor, int lda,
+                                        const float* bias1T, const float* bias2T, const float* logit1, const float* logit2,
+                                        float* out, int ldo, int ocol0, int B, int H, int W, int heads, int hd, void* stream) {
+  FFSR_CHECK(qkv && anchor && bias1T && bias2T && logit1 && logit2 && out && B > 0 && H % 8 == 0 && W % 8 == 0 && heads > 0);
+  dim3 grid((H / 8) * (W / 8) * B, heads);
+  switch (hd) {
+    case 30: hipLaunchKernelGGL(grl_stripe_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
+    case 10: hipLaunchKernelGGL(grl_stripe_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
+    default: return FFSR_EINVAL;
+  }
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo, long long S, int T, int E, int heads,
+                                  void* stream) {
+  FFSR_CHECK(qkv && out && S > 0 && heads > 0 && E == heads * 16 && (ldq % 4) == 0 && (ldo % 4) == 0);
+  FFSR_CHECK(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0);
+  long long n = S * T * heads;
+  dim3 grid((unsigned)((n + 255) / 256));
+  switch (T) {
+    case 9: hipLaunchKernelGGL(pixel_mha_kernel<9>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
+    case 4: hipLaunchKernelGGL(pixel_mha_kernel<4>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
+    default: return FFSR_EINVAL;
+  }
+  return ffsr_launch_status();
+}

@@ -1,0 +1,211 @@
+// Fused HR-resolution elementwise stages of the 7-phase fusion, gfx950.  All are HBM-bound:
+// one pass over the expert stack instead of the reference's dozens of full-resolution temporaries.
+#include "ffsr_common.h"
+
+namespace {
+
+struct Bil {
+  int y0, y1, x0, x1;
+  float ly, lx;
+};
+__device__ __forceinline__ void coord(int d, float scale, int n, int& i0, int& i1, float& l) {
+  float s = ((float)d + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > n - 1) i0 = n - 1;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l = s - (float)i0;
+}
+__device__ __forceinline__ Bil make_bil(int y, int x, int h, int w, float sh, float sw) {
+  Bil b;
+  coord(y, sh, h, b.y0, b.y1, b.ly);
+  coord(x, sw, w, b.x0, b.x1, b.lx);
+  return b;
+}
+__device__ __forceinline__ float sample(const float* base, int ld, int w, const Bil& b, int c) {
+  const float v00 = base[((size_t)b.y0 * w + b.x0) * ld + c], v01 = base[((size_t)b.y0 * w + b.x1) * ld + c];
+  const float v10 = base[((size_t)b.y1 * w + b.x0) * ld + c], v11 = base[((size_t)b.y1 * w + b.x1) * ld + c];
+  return (1.f - b.ly) * ((1.f - b.lx) * v00 + b.lx * v01) + b.ly * ((1.f - b.lx) * v10 + b.lx * v11);
+}
+__device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// gates = sigmoid(T * (raw - (0.7 - 0.5 * diff))) / clamp(sum + 1e-8, min 0.3)     enhanced_fusion_v2.py:462-465
+__global__ void selector_gates_kernel(const float* __restrict__ raw, int ldr, const float* __restrict__ diff, int ldd,
+                                      const float* __restrict__ temp, float* __restrict__ gates, int ldg, long long M) {
+  long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float thr = 0.7f - 0.5f * diff[m * ldd];
+  const float T = temp[0];
+  float g[4], s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    g[e] = 1.0f / (1.0f + expf(-(T * (raw[m * ldr + e] - thr))));
+    s += g[e];
+  }
+  s = fmaxf(s + 1e-8f, 0.3f);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gates[m * ldg + e] = g[e] / s;
+}
+
+// phase 4 tail.  t_lr = conv1x1(128->32)(lka_out) at LR (hoisted before the bilinear: both are linear);
+// mod = sigmoid(W2 gelu(bilinear(t_lr)) + b2); out = clamp(img * (1 + 0.2 (mod - 0.5)), 0, 1)
+__global__ void modulate_kernel(const float* __restrict__ t_lr, int ldt, const float* __restrict__ w2,
+                                const float* __restrict__ b2, const float* __restrict__ img, int ldi, float* __restrict__ out,
+                                int ldo, int B, int h, int w, int Hh, int Wh, float sh, float sw) {
+  __shared__ float W2[96], B2[3];
+  if (threadIdx.x < 96) W2[threadIdx.x] = w2[threadIdx.x];
+  if (threadIdx.x < 3) B2[threadIdx.x] = b2[threadIdx.x];
+  __syncthreads();
+  long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long long)B * Hh * Wh) return;
+  const int x = (int)(pix % Wh);
+  long long t = pix / Wh;
+  const int y = (int)(t % Hh), b = (int)(t / Hh);
+  const Bil bl = make_bil(y, x, h, w, sh, sw);
+  const float* base = t_lr + (size_t)b * h * w * ldt;
+  const float* p00 = base + ((size_t)bl.y0 * w + bl.x0) * ldt;
+  const float* p01 = base + ((size_t)bl.y0 * w + bl.x1) * ldt;
+  const float* p10 = base + ((size_t)bl.y1 * w + bl.x0) * ldt;
+  const float* p11 = base + ((size_t)bl.y1 * w + bl.x1) * ldt;
+  const float hy = 1.f - bl.ly, hx = 1.f - bl.lx;
+  float m0 = B2[0], m1 = B2[1], m2 = B2[2];
+#pragma unroll
+  for (int c4 = 0; c4 < 32; c4 += 4) {
+    const floatx4 a = *reinterpret_cast<const floatx4*>(p00 + c4), bb = *reinterpret_cast<const floatx4*>(p01 + c4);
+    const floatx4 cc = *reinterpret_cast<const floatx4*>(p10 + c4), d = *reinterpret_cast<const floatx4*>(p11 + c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u = gelu(hy * (hx * a[i] + bl.lx * bb[i]) + bl.ly * (hx * cc[i] + bl.lx * d[i]));
+      m0 = fmaf(W2[c4 + i], u, m0);
+      m1 = fmaf(W2[32 + c4 + i], u, m1);
+      m2 = fmaf(W2[64 + c4 + i], u, m2);
+    }
+  }
+  const float mm[3] = {m0, m1, m2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float mod = 1.0f / (1.0f + expf(-mm[c]));
+    const float v = img[pix * ldi + c] * (1.0f + 0.2f * (mod - 0.5f));
+    out[pix * ldo + c] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+
+// phases 5b + 5c + 6 (enhanced_fusion_v2.py:735-774).  fw = [W1 16x3 | b1 16 | W2 4x16 | b2 4] of freq_weight_conv.
+__global__ void route_kernel(const float* __restrict__ enh, int lde, const float* __restrict__ hier, int ldh,
+                             const float* __restrict__ routing, int ldr, const float* __restrict__ fw,
+                             const float* __restrict__ gates, int ldg, const float* __restrict__ diff, int ldd,
+                             float* __restrict__ out, int ldo, int B, int h, int w, int Hh, int Wh, float sh, float sw) {
+  __shared__ float F[132];
+  if (threadIdx.x < 132) F[threadIdx.x] = fw[threadIdx.x];
+  __syncthreads();
+  long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long long)B * Hh * Wh) return;
+  const int x = (int)(pix % Wh);
+  long long t = pix / Wh;
+  const int y = (int)(t % Hh), b = (int)(t / Hh);
+  const Bil bl = make_bil(y, x, h, w, sh, sw);
+  const size_t lrb = (size_t)b * h * w;
+  // frequency-guided expert weights
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r[c] = sample(routing + lrb * ldr, ldr, w, bl, c);
+  float lg[4] = {F[128], F[129], F[130], F[131]};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float hdn = gelu(F[48 + j] + F[j * 3] * r[0] + F[j * 3 + 1] * r[1] + F[j * 3 + 2] * r[2]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lg[e] = fmaf(F[64 + e * 16 + j], hdn, lg[e]);
+  }
+  const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+  float wt[4], ws = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    wt[e] = expf(lg[e] - mx);
+    ws += wt[e];
+  }
+  float g[4], gs = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    wt[e] /= ws;
+    g[e] = sample(gates + lrb * ldg, ldg, w, bl, e);
+    gs += g[e];
+  }
+  gs += 1e-8f;
+  const float bw = 0.3f + 0.4f * sample(diff + lrb * ldd, ldd, w, bl, 0);
+  const float* ep = enh + pix * lde;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float fq = 0.f, dy = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = ep[3 * e + c];
+      fq += v * wt[e];
+      dy += v * g[e];
+    }
+    const float fused = hier[pix * ldh + c] * 0.7f + fq * 0.3f;
+    out[pix * ldo + c] = (1.f - bw) * fused + bw * (dy / gs);
+  }
+  out[pix * ldo + 3] = 0.f;
+}
+
+// enhanced = clamp(sr + gate * strength * edge, 0, 1); out = clamp(enhanced + rscale * bilinear(lr), 0, 1)
+__global__ void edge_final_kernel(const float* __restrict__ sr, int lds, const float* __restrict__ edge, int lde,
+                                  const float* __restrict__ gate, int ldg, const float* __restrict__ strength,
+                                  const float* __restrict__ lr, int ldl, const float* __restrict__ rscale, float* __restrict__ out,
+                                  int ldo, int B, int h, int w, int Hh, int Wh, float sh, float sw) {
+  long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long long)B * Hh * Wh) return;
+  const int x = (int)(pix % Wh);
+  long long t = pix / Wh;
+  const int y = (int)(t % Hh), b = (int)(t / Hh);
+  const Bil bl = make_bil(y, x, h, w, sh, sw);
+  const float gs = gate[pix * ldg] * strength[0];
+  const float rs = rscale[0];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = sr[pix * lds + c] + gs * edge[pix * lde + c];
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    v += rs * sample(lr + (size_t)b * h * w * ldl, ldl, w, bl, c);
+    out[pix * ldo + c] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+
+inline int grid_for(long long n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int ffsr_selector_gates_f32(const float* raw, int ldr, const float* diff, int ldd, const float* temperature,
+                                       float* gates, int ldg, long long M, void* stream) {
+  FFSR_CHECK(raw && diff && temperature && gates && M > 0);
+  hipLaunchKernelGGL(selector_gates_kernel, dim3(grid_for(M)), dim3(256), 0, ST, raw, ldr, diff, ldd, temperature, gates, ldg, M);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_modulate_f32(const float* t_lr, int ldt, const float* w2, const float* b2, const float* img, int ldi,
+                                 float* out, int ldo, int B, int h, int w, int Hh, int Wh, void* stream) {
+  FFSR_CHECK(t_lr && w2 && b2 && img && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0 && (ldt % 4) == 0 && ldt >= 32);
+  FFSR_CHECK(((uintptr_t)t_lr & 15) == 0);
+  hipLaunchKernelGGL(modulate_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, t_lr, ldt, w2, b2, img, ldi, out,
+                     ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_fusion_route_f32(const float* enh, int lde, const float* hier, int ldh, const float* routing, int ldr,
+                                     const float* fw, const float* gates, int ldg, const float* diff, int ldd, float* out,
+                                     int ldo, int B, int h, int w, int Hh, int Wh, void* stream) {
+  FFSR_CHECK(enh && hier && routing && fw && gates && diff && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0 && ldo >= 4);
+  hipLaunchKernelGGL(route_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, enh, lde, hier, ldh, routing, ldr,
+                     fw, gates, ldg, diff, ldd, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, const float* gate, int ldg,
+                                   const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo,
+                                   int B, int h, int w, int Hh, int Wh, void* stream) {
+  FFSR_CHECK(sr && edge && gate && strength && lr && rscale && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0);
+  hipLaunchKernelGGL(edge_final_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, sr, lds, edge, lde, gate, ldg,
+                     strength, lr, ldl, rscale, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
+  return ffsr_launch_status();
+}

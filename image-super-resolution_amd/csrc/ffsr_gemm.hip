@@ -1,0 +1,251 @@
+// Implicit-GEMM convolution / token GEMM on the fp32-input MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+//   out[m, n] = epi( sum_k A[m, k] * Wt[n, k] )        m = output pixel (b, oy, ox), n = output channel
+//   A[m, (ky, kx, ci)] = in[b, oy*stride - pad + ky, ox*stride - pad + kx, ci]   (NHWC, zero padded)
+//
+// This one kernel is K5/K6/K12/K15 of SURVEY.md section 2.3: every nn.Linear / 1x1 conv (KH=KW=1) and every
+// dense kxk conv of the four experts and the fusion net.  Numerics: the f32 MFMA is an exact k-ordered
+// fmaf chain, i.e. the same arithmetic class as the reference's fp32 CPU path.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 32; each wave owns TM x TN tiles of 32x32.
+// A and B tiles are staged global -> registers -> LDS (double buffered, one barrier per K step); fragments are
+// read as ds_read_b128 with a 36-float row stride (conflict-free for the b128 lane groups).  Inside a group
+// of 8 k's lane-half h holds k = 8j+4h..8j+4h+3, MFMA step s contracts k = 8j+s and 8j+4+s (both operands use
+// the same permutation, so the sum is unchanged).  blockIdx -> tile mapping is XCD-aware: the tiles of one
+// XCD are consecutive (same A rows, neighbouring N tiles) so A is fetched into one L2 only.
+#include "ffsr_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LSTR = 36;  // LDS row stride in floats (36/4 = 9 odd -> b128 reads conflict-free)
+
+struct ConvArgs {
+  const float* in;
+  const float* wgt;
+  const float* bias;
+  float* out;
+  const float* res;
+  const float* cvec;
+  const float* rvec;
+  const float* akscale;
+  int B, H, W, Cin, ldi;
+  int N, Ho, Wo, ldo, ldr, ldw;
+  int KH, KW, stride, pad_h, pad_w;
+  int act;
+  float slope, cscale, rscale;
+  int shuffle;
+  int M, Ktot, akrows;  // akrows = rows (pixels) per akscale batch
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread in the loaders
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LSTR];
+
+  // ---- XCD-aware tile id (bijective for any grid size)
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+  const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kofs = (tid & 7) * 4;
+  const int rbase = tid >> 3;
+
+  // ---- per-row state of the A loader
+  int a_iy0[AR], a_ix0[AR], a_pix[AR];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + rbase + 32 * i;
+    if (m < p.M) {
+      int b = m / HoWo, rem = m - b * HoWo;
+      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[i] = oy * p.stride - p.pad_h;
+      a_ix0[i] = ox * p.stride - p.pad_w;
+      a_pix[i] = b * p.H * p.W;
+    } else {
+      a_iy0[i] = -(1 << 28);  // always out of bounds
+      a_ix0[i] = 0;
+      a_pix[i] = 0;
+    }
+  }
+
+  floatx4 a_reg[AR], b_reg[BR];
+  const bool is1x1 = (p.KH * p.KW == 1);
+
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + kofs;
+    const bool kval = k < p.Ktot;
+    int ky = 0, kx = 0, ci = k;
+    if (!is1x1) {
+      int tap = k / p.Cin;
+      ci = k - tap * p.Cin;
+      ky = tap / p.KW;
+      kx = tap - ky * p.KW;
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int yy = a_iy0[i] + ky, xx = a_ix0[i] + kx;
+      bool ok = kval && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        size_t off = (size_t)(a_pix[i] + yy * p.W + xx) * p.ldi + ci;
+        v = *reinterpret_cast<const floatx4*>(p.in + off);
+        if (p.akscale) {
+          int m = m0 + rbase + 32 * i;
+          const floatx4 s = *reinterpret_cast<const floatx4*>(p.akscale + (size_t)(m / p.akrows) * p.Ktot + k);
+          v *= s;
+        }
+      }
+      a_reg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      int n = n0 + rbase + 32 * i;
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kval && n < p.N) v = *reinterpret_cast<const floatx4*>(p.wgt + (size_t)n * p.ldw + k);
+      b_reg[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* As = smem[buf];
+    float* Bs = As + BM * LSTR;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<floatx4*>(As + (rbase + 32 * i) * LSTR + kofs) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<floatx4*>(Bs + (rbase + 32 * i) * LSTR + kofs) = b_reg[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wrow = (wave / WAVES_N) * WM, wcol = (wave % WAVES_N) * WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (p.Ktot + BK - 1) / BK;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float* As = smem[kt & 1];
+    const float* Bs = As + BM * LSTR;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      floatx4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const floatx4*>(As + (wrow + i * 32 + r) * LSTR + 8 * j + 4 * h);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        bf[i] = *reinterpret_cast<const floatx4*>(Bs + (wcol + i * 32 + r) * LSTR + 8 * j + 4 * h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[jj][s], acc[i][jj], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + wcol + jn * 32 + r;
+    if (n >= p.N) continue;
+    const float bia = p.bias ? p.bias[n] : 0.f;
+    const float cs = (p.cvec ? p.cvec[n] : 1.f) * p.cscale;
+    const float rs = (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wrow + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = ffsr_act(acc[im][jn][e] + bia, p.act, p.slope) * cs;
+        size_t opix;
+        int oc = n;
+        if (p.shuffle) {
+          int b = m / HoWo, rem = m - b * HoWo;
+          int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          oc = n >> 2;
+          opix = ((size_t)b * 2 * p.Ho + 2 * oy + ((n >> 1) & 1)) * (2 * p.Wo) + 2 * ox + (n & 1);
+        } else {
+          opix = (size_t)m;
+        }
+        if (p.res) v += p.res[opix * p.ldr + oc] * rs;
+        p.out[opix * p.ldo + oc] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a, hipStream_t st) {
+  int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(tiles), dim3(256), 0, st, a);
+  return ffsr_launch_status();
+}
+
+}  // namespace
+
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_conv2d_f32(const float* in, const float* wgt, const float* bias, float* out, const float* res,
+                               const float* cvec, const float* rvec, const float* akscale, int B, int H, int W,
+                               int Cin, int ldi, int N, int ldo, int ldr, int KH, int KW, int stride, int pad_h,
+                               int pad_w, int act, float slope, float cscale, float rscale, int shuffle,
+                               int akrows, int tile_hint, void* stream) {
+  FFSR_CHECK(in && wgt && out);
+  FFSR_CHECK(B > 0 && H > 0 && W > 0 && N > 0 && KH > 0 && KW > 0 && stride > 0);
+  FFSR_CHECK(Cin > 0 && (Cin & 3) == 0 && (ldi & 3) == 0 && ldi >= Cin);
+  FFSR_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)wgt & 15) == 0);
+  FFSR_CHECK(shuffle == 0 || (shuffle == 2 && (N & 3) == 0));
+  FFSR_CHECK(!akscale || (KH * KW == 1 && akrows > 0 && ((uintptr_t)akscale & 15) == 0));
+  ConvArgs a;
+  a.in = in; a.wgt = wgt; a.bias = bias; a.out = out; a.res = res; a.cvec = cvec; a.rvec = rvec; a.akscale = akscale;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldi = ldi; a.N = N;
+  a.Ho = (H + 2 * pad_h - KH) / stride + 1;
+  a.Wo = (W + 2 * pad_w - KW) / stride + 1;
+  FFSR_CHECK(a.Ho > 0 && a.Wo > 0);
+  a.ldo = ldo; a.ldr = ldr; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.act = act; a.slope = slope; a.cscale = cscale; a.rscale = rscale; a.shuffle = shuffle;
+  a.Ktot = KH * KW * Cin; a.ldw = a.Ktot; a.akrows = akrows > 0 ? akrows : 1;
+  long long M = (long long)B * a.Ho * a.Wo;
+  FFSR_CHECK(M < (1ll << 31) && (long long)B * H * W < (1ll << 31));
+  a.M = (int)M;
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice: minimise padded columns; tile_hint overrides (1: 128x128, 2: 128x64, 3: 256x32, 4: 64x64)
+  int choice = tile_hint;
+  if (choice == 0) {
+    if (N <= 32) choice = 3;
+    else {
+      int w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
+      choice = (w128 == w64) ? 1 : 2;
+    }
+    if (a.M <= 64 * 24 && N > 32) choice = 4;
+  }
+  switch (choice) {
+    case 1: return launch<128, 128, 2, 2>(a, st);
+    case 2: return launch<128, 64, 2, 2>(a, st);
+    case 3: return launch<256, 32, 4, 1>(a, st);
+    case 4: return launch<64, 64, 2, 2>(a, st);
+    default: return FFSR_EINVAL;
+  }
+}

@@ -1,0 +1,559 @@
+// HBM-bound row/pixel kernels on channels-last (NHWC) fp32 tensors, gfx950:
+// LayerNorm over channels, elementwise combinators, column means, depthwise convolutions (incl. NAFNet's
+// dw3x3 + SimpleGate + pooled partial sums), bilinear / bicubic resamplers, 2x2 average pooling.
+// A tensor is a matrix [M pixels, C channels] with a row stride ld (floats, multiple of 4 so that every row is
+// 16-byte aligned); lanes run along channels so every wave access is a contiguous row segment.
+#include "ffsr_common.h"
+
+namespace {
+
+template <int V> struct Vec;
+template <> struct Vec<4> { using T = floatx4; };
+template <> struct Vec<1> { using T = float; };
+
+template <int V> __device__ __forceinline__ typename Vec<V>::T ld(const float* p) {
+  return *reinterpret_cast<const typename Vec<V>::T*>(p);
+}
+template <int V> __device__ __forceinline__ void st(float* p, typename Vec<V>::T v) {
+  *reinterpret_cast<typename Vec<V>::T*>(p) = v;
+}
+__device__ __forceinline__ float elem(const float& v, int) { return v; }
+__device__ __forceinline__ float elem(const floatx4& v, int i) { return v[i]; }
+__device__ __forceinline__ void set(float& v, int, float x) { v = x; }
+__device__ __forceinline__ void set(floatx4& v, int i, float x) { v[i] = x; }
+
+inline int grid_for(long long n, int block = 256) { return (int)((n + block - 1) / block); }
+
+// ------------------------------------------------------------------------------------------- LayerNorm
+// one wave per row, up to 16 elements per lane (C <= 1024)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float eps, float* __restrict__ out,
+                                                        int ldo, const float* __restrict__ r1, int ldr1,
+                                                        const float* __restrict__ r2, int ldr2, int M, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + 64 * i;
+    v[i] = c < C ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + 64 * i;
+    float d = c < C ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + 64 * i;
+    if (c < C) {
+      float y = (v[i] - mean) * rstd * g[c] + b[c];
+      if (r1) y += r1[(size_t)row * ldr1 + c];
+      if (r2) y += r2[(size_t)row * ldr2 + c];
+      out[(size_t)row * ldo + c] = y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- elementwise
+// out = clamp( act(x * pre) * alpha * cscale[n] + beta + cbias[n] )
+template <int V>
+__global__ void unary_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo, long long M, int C,
+                             int act, float slope, float pre, float alpha, float beta, const float* __restrict__ cscale, const float* __restrict__ cbias,
+                             int do_clamp, float lo, float hi) {
+  const int cv = C / V;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * cv) return;
+  long long m = idx / cv;
+  int c = (int)(idx - m * cv) * V;
+  auto v = ld<V>(x + m * ldx + c);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float y = ffsr_act(elem(v, i) * pre, act, slope) * alpha;
+    if (cscale) y *= cscale[c + i];
+    y += beta;
+    if (cbias) y += cbias[c + i];
+    if (do_clamp) y = fminf(fmaxf(y, lo), hi);
+    set(v, i, y);
+  }
+  st<V>(out + m * ldo + c, v);
+}
+
+// out = alpha * a * avec[n] + beta * b * bvec[batch(m), n]      (b / avec / bvec optional)
+template <int V>
+__global__ void scale_add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ avec,
+                                 const float* __restrict__ b, int ldb, const float* __restrict__ bvec, int rows_per_batch,
+                                 float* __restrict__ out, int ldo, long long M, int C, float alpha, float beta) {
+  const int cv = C / V;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * cv) return;
+  long long m = idx / cv;
+  int c = (int)(idx - m * cv) * V;
+  auto va = ld<V>(a + m * lda + c);
+  typename Vec<V>::T vb = va;
+  if (b) vb = ld<V>(b + m * ldb + c);
+  const float* bv = bvec ? bvec + (size_t)(m / rows_per_batch) * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float y = alpha * elem(va, i) * (avec ? avec[c + i] : 1.f);
+    if (b) y += beta * elem(vb, i) * (bv ? bv[c + i] : 1.f);
+    set(va, i, y);
+  }
+  st<V>(out + m * ldo + c, va);
+}
+
+// out = alpha * a * b' + gamma * c     b' = b[m, n] (bmode 0) or b[m] broadcast over channels (bmode 1); c optional
+template <int V>
+__global__ void mul_add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmode,
+                               const float* __restrict__ cc, int ldc, float* __restrict__ out, int ldo, long long M, int C,
+                               float alpha, float gamma) {
+  const int cv = C / V;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * cv) return;
+  long long m = idx / cv;
+  int c = (int)(idx - m * cv) * V;
+  auto va = ld<V>(a + m * lda + c);
+  typename Vec<V>::T vb = va, vc = va;
+  float bs = 0.f;
+  if (bmode == 0) vb = ld<V>(b + m * ldb + c);
+  else bs = b[m * ldb];
+  if (cc) vc = ld<V>(cc + m * ldc + c);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float y = alpha * elem(va, i) * (bmode == 0 ? elem(vb, i) : bs);
+    if (cc) y += gamma * elem(vc, i);
+    set(va, i, y);
+  }
+  st<V>(out + m * ldo + c, va);
+}
+
+// ------------------------------------------------------------------------------------------- column sums
+// part[b, chunk, c] = sum over the rows of the chunk;  grid = (ceil(C/64), nchunk, B), block 256 = 64 ch x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx, float* __restrict__ part,
+                                                             int R, int C, int nchunk) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int per = (R + nchunk - 1) / nchunk;
+  const int r0 = chunk * per, r1 = min(R, r0 + per);
+  float s = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[((size_t)b * R + r) * ldx + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    part[((size_t)b * nchunk + chunk) * C + c] = s;
+  }
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C, int nchunk,
+                                     float scale) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  int b = idx / C, c = idx - b * C;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * C + c];
+  out[idx] = s * scale;
+}
+
+// ------------------------------------------------------------------------------------------- depthwise conv
+// weights tap-major [KH*KW, C]; stride 1; zero padding
+template <int V>
+__global__ void dwconv_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w, const float* __restrict__ bias,
+                              float* __restrict__ out, int ldo, int B, int H, int W, int C, int KH, int KW, int ph, int pw,
+                              int act) {
+  const int cv = C / V;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * H * W * cv;
+  if (idx >= total) return;
+  long long pix = idx / cv;
+  int c = (int)(idx - pix * cv) * V;
+  int x = (int)(pix % W);
+  long long t = pix / W;
+  int y = (int)(t % H);
+  int b = (int)(t / H);
+  typename Vec<V>::T acc;
+#pragma unroll
+  for (int i = 0; i < V; ++i) set(acc, i, bias ? bias[c + i] : 0.f);
+  for (int ky = 0; ky < KH; ++ky) {
+    int yy = y + ky - ph;
+    if (yy < 0 || yy >= H) continue;
+    for (int kx = 0; kx < KW; ++kx) {
+      int xx = x + kx - pw;
+      if (xx < 0 || xx >= W) continue;
+      auto v = ld<V>(in + (((size_t)b * H + yy) * W + xx) * ldi + c);
+      auto wv = ld<V>(w + (size_t)(ky * KW + kx) * C + c);
+#pragma unroll
+      for (int i = 0; i < V; ++i) set(acc, i, fmaf(elem(v, i), elem(wv, i), elem(acc, i)));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) set(acc, i, ffsr_act(elem(acc, i), act, 0.f));
+  st<V>(out + pix * ldo + c, acc);
+}
+
+// NAFNet: t = dw3x3(in [.., 2C]) ; out[.., c] = t[c] * t[c + C] ; part[b, chunk, c] = sum over the chunk's pixels
+// grid = (ceil(C/64), nchunk, B); block 256 = 64 channels x 4 pixel lanes; chunk = contiguous pixel range
+__global__ __launch_bounds__(256) void dw3x3_gate_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                         float* __restrict__ part, int H, int W, int C, int nchunk) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int R = H * W;
+  const int per = (R + nchunk - 1) / nchunk;
+  const int r0 = chunk * per, r1 = min(R, r0 + per);
+  float s = 0.f;
+  if (c < C) {
+    float w1[9], w2[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      w1[k] = w[k * 2 * C + c];
+      w2[k] = w[k * 2 * C + C + c];
+    }
+    const float b1 = bias[c], b2 = bias[C + c];
+    for (int r = r0 + pl; r < r1; r += 4) {
+      int y = r / W, x = r - y * W;
+      float a1 = b1, a2 = b2;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        int yy = y + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          int xx = x + kx - 1;
+          if (xx < 0 || xx >= W) continue;
+          const float* p = in + (((size_t)b * H + yy) * W + xx) * ldi;
+          a1 = fmaf(p[c], w1[ky * 3 + kx], a1);
+          a2 = fmaf(p[C + c], w2[ky * 3 + kx], a2);
+        }
+      }
+      float g = a1 * a2;
+      out[((size_t)b * R + r) * ldo + c] = g;
+      s += g;
+    }
+  }
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C)
+    part[((size_t)b * nchunk + chunk) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------- resamplers
+// torch F.interpolate(mode='bilinear', align_corners=False, size=(Ho,Wo)): src = (dst+0.5)*in/out - 0.5 clamped at 0
+__device__ __forceinline__ void bilin_coord(int d, float scale, int n, int& i0, int& i1, float& l) {
+  float s = ((float)d + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > n - 1) i0 = n - 1;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l = s - (float)i0;
+}
+template <int V>
+__global__ void bilinear_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int Hi, int Wi,
+                                int Ho, int Wo, int C, float sh, float sw, float mul, int accumulate) {
+  const int cv = C / V;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * Ho * Wo * cv;
+  if (idx >= total) return;
+  long long pix = idx / cv;
+  int c = (int)(idx - pix * cv) * V;
+  int x = (int)(pix % Wo);
+  long long t = pix / Wo;
+  int y = (int)(t % Ho);
+  int b = (int)(t / Ho);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilin_coord(y, sh, Hi, y0, y1, ly);
+  bilin_coord(x, sw, Wi, x0, x1, lx);
+  const float* base = in + (size_t)b * Hi * Wi * ldi + c;
+  auto v00 = ld<V>(base + ((size_t)y0 * Wi + x0) * ldi);
+  auto v01 = ld<V>(base + ((size_t)y0 * Wi + x1) * ldi);
+  auto v10 = ld<V>(base + ((size_t)y1 * Wi + x0) * ldi);
+  auto v11 = ld<V>(base + ((size_t)y1 * Wi + x1) * ldi);
+  float* op = out + pix * ldo + c;
+  typename Vec<V>::T o;
+  if (accumulate) o = ld<V>(op);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+    float r = hy * (hx * elem(v00, i) + lx * elem(v01, i)) + ly * (hx * elem(v10, i) + lx * elem(v11, i));
+    r *= mul;
+    set(o, i, accumulate ? elem(o, i) + r : r);
+  }
+  st<V>(op, o);
+}
+
+// torch bicubic (A = -0.75), align_corners=False, scale_factor=4: src = (dst+0.5)/4 - 0.5, taps clamped to the border
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+  const float A = -0.75f;
+  float x = t + 1.f;
+  w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t;
+  w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t;
+  w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t;
+  w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+__global__ void bicubic_up_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int H, int W,
+                                  int C, int scale) {
+  const int Ho = H * scale, Wo = W * scale;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * Ho * Wo * C;
+  if (idx >= total) return;
+  long long pix = idx / C;
+  int c = (int)(idx - pix * C);
+  int x = (int)(pix % Wo);
+  long long t = pix / Wo;
+  int y = (int)(t % Ho);
+  int b = (int)(t / Ho);
+  const float inv = 1.0f / (float)scale;
+  float sy = ((float)y + 0.5f) * inv - 0.5f, sx = ((float)x + 0.5f) * inv - 0.5f;
+  int iy = (int)floorf(sy), ix = (int)floorf(sx);
+  float wy[4], wx[4];
+  cubic_w(sy - (float)iy, wy);
+  cubic_w(sx - (float)ix, wx);
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int yy = min(max(iy - 1 + j, 0), H - 1);
+    float row = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int xx = min(max(ix - 1 + i, 0), W - 1);
+      row += in[(((size_t)b * H + yy) * W + xx) * ldi + c] * wx[i];
+    }
+    acc += row * wy[j];
+  }
+  out[pix * ldo + c] = acc;
+}
+
+template <int V>
+__global__ void avgpool2_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int H, int W,
+                                int C) {
+  const int Ho = H / 2, Wo = W / 2, cv = C / V;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * Ho * Wo * cv;
+  if (idx >= total) return;
+  long long pix = idx / cv;
+  int c = (int)(idx - pix * cv) * V;
+  int x = (int)(pix % Wo);
+  long long t = pix / Wo;
+  int y = (int)(t % Ho);
+  int b = (int)(t / Ho);
+  const float* p = in + (((size_t)b * H + 2 * y) * W + 2 * x) * ldi + c;
+  auto a = ld<V>(p), b2 = ld<V>(p + ldi), c2 = ld<V>(p + (size_t)W * ldi), d = ld<V>(p + (size_t)W * ldi + ldi);
+#pragma unroll
+  for (int i = 0; i < V; ++i) set(a, i, (elem(a, i) + elem(b2, i) + elem(c2, i) + elem(d, i)) * 0.25f);
+  st<V>(out + pix * ldo + c, a);
+}
+
+// ------------------------------------------------------------------------------------------- image I/O helpers
+// uint8 HWC -> float/255 (io.py:100-104); channels beyond C in the output row are left untouched (zero padded buffer)
+__global__ void u8_to_f32_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int ldo, long long M, int C) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * C) return;
+  long long m = idx / C;
+  int c = (int)(idx - m * C);
+  out[m * ldo + c] = (float)in[idx] / 255.0f;
+}
+// clamp(0,1) * 255 -> round half to even -> uint8 (io.py:107-112; numpy round == rintf)
+__global__ void f32_to_u8_kernel(const float* __restrict__ in, int ldi, unsigned char* __restrict__ out, long long M, int C) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * C) return;
+  long long m = idx / C;
+  int c = (int)(idx - m * C);
+  float v = fminf(fmaxf(in[m * ldi + c], 0.f), 1.f) * 255.0f;
+  out[idx] = (unsigned char)rintf(v);
+}
+// F.pad(x, (0, pw, 0, ph), mode='reflect') (io.py:71-78): right / bottom only
+__global__ void pad_reflect_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int H, int W,
+                                   int Hp, int Wp, int C) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * Hp * Wp * C) return;
+  int c = (int)(idx % C);
+  long long pix = idx / C;
+  int x = (int)(pix % Wp);
+  long long t = pix / Wp;
+  int y = (int)(t % Hp), b = (int)(t / Hp);
+  int ys = y < H ? y : 2 * (H - 1) - y, xs = x < W ? x : 2 * (W - 1) - x;
+  out[pix * ldo + c] = in[(((size_t)b * H + ys) * W + xs) * ldi + c];
+}
+// crop the top-left [Ho, Wo] window (io.py:81-83 and the feature crops :234,245,268)
+__global__ void crop_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int H, int W, int Ho,
+                            int Wo, int C, int do_clamp) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * Ho * Wo * C) return;
+  int c = (int)(idx % C);
+  long long pix = idx / C;
+  int x = (int)(pix % Wo);
+  long long t = pix / Wo;
+  int y = (int)(t % Ho), b = (int)(t / Ho);
+  float v = in[(((size_t)b * H + y) * W + x) * ldi + c];
+  if (do_clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+  out[pix * ldo + c] = v;
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int ffsr_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out,
+                                  int ldo, const float* res1, int ldr1, const float* res2, int ldr2, int M, int C,
+                                  void* stream) {
+  FFSR_CHECK(x && gamma && beta && out && M > 0 && C > 0 && C <= 1024 && ldx >= C && ldo >= C);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, ldx, gamma, beta, eps, out, ldo, res1, ldr1,
+                     res2, ldr2, M, C);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_unary_f32(const float* x, int ldx, float* out, int ldo, long long M, int C, int act, float slope,
+                              float pre, float alpha, float beta, const float* cscale, const float* cbias, int do_clamp,
+                              float lo, float hi, void* stream) {
+  FFSR_CHECK(x && out && M > 0 && C > 0);
+  bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && al16(x) && al16(out);
+  if (v4)
+    hipLaunchKernelGGL(unary_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, x, ldx, out, ldo, M, C, act, slope,
+                       pre, alpha, beta, cscale, cbias, do_clamp, lo, hi);
+  else
+    hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, x, ldx, out, ldo, M, C, act, slope, pre, alpha,
+                       beta, cscale, cbias, do_clamp, lo, hi);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_scale_add_f32(const float* a, int lda, const float* avec, const float* b, int ldb, const float* bvec,
+                                  int rows_per_batch, float* out, int ldo, long long M, int C, float alpha, float beta,
+                                  void* stream) {
+  FFSR_CHECK(a && out && M > 0 && C > 0 && rows_per_batch > 0);
+  bool v4 = (C % 4 == 0) && (lda % 4 == 0) && (ldo % 4 == 0) && (!b || ldb % 4 == 0) && al16(a) && al16(out) && (!b || al16(b));
+  if (v4)
+    hipLaunchKernelGGL(scale_add_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, a, lda, avec, b, ldb, bvec,
+                       rows_per_batch, out, ldo, M, C, alpha, beta);
+  else
+    hipLaunchKernelGGL(scale_add_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, a, lda, avec, b, ldb, bvec,
+                       rows_per_batch, out, ldo, M, C, alpha, beta);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_mul_add_f32(const float* a, int lda, const float* b, int ldb, int bmode, const float* c, int ldc,
+                                float* out, int ldo, long long M, int C, float alpha, float gamma, void* stream) {
+  FFSR_CHECK(a && b && out && M > 0 && C > 0 && (bmode == 0 || bmode == 1));
+  bool v4 = (C % 4 == 0) && (lda % 4 == 0) && (ldo % 4 == 0) && (bmode == 1 || ldb % 4 == 0) && (!c || ldc % 4 == 0) &&
+            al16(a) && al16(out) && (bmode == 1 || al16(b)) && (!c || al16(c));
+  if (v4)
+    hipLaunchKernelGGL(mul_add_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, a, lda, b, ldb, bmode, c, ldc, out,
+                       ldo, M, C, alpha, gamma);
+  else
+    hipLaunchKernelGGL(mul_add_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, a, lda, b, ldb, bmode, c, ldc, out, ldo,
+                       M, C, alpha, gamma);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part, int B, int R, int C, int nchunk,
+                                void* stream) {
+  FFSR_CHECK(x && out && part && B > 0 && R > 0 && C > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0, ST, part, out, B, C, nchunk,
+                     1.0f / (float)R);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo, int B,
+                                 int H, int W, int C, int KH, int KW, int pad_h, int pad_w, int act, void* stream) {
+  FFSR_CHECK(in && w && out && B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0);
+  long long pix = (long long)B * H * W;
+  bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out) && al16(w);
+  if (v4)
+    hipLaunchKernelGGL(dwconv_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W,
+                       C, KH, KW, pad_h, pad_w, act);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W, C,
+                       KH, KW, pad_h, pad_w, act);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                                        float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream) {
+  FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
+  hipLaunchKernelGGL(dw3x3_gate_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part, H,
+                     W, C, nchunk);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0, ST, part, pooled, B, C, nchunk,
+                     1.0f / (float)(H * W));
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_bilinear_f32(const float* in, int ldi, float* out, int ldo, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                 float mul, int accumulate, void* stream) {
+  FFSR_CHECK(in && out && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0);
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  long long pix = (long long)B * Ho * Wo;
+  bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out);
+  if (v4)
+    hipLaunchKernelGGL(bilinear_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi, Wi, Ho,
+                       Wo, C, sh, sw, mul, accumulate);
+  else
+    hipLaunchKernelGGL(bilinear_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi, Wi, Ho, Wo, C,
+                       sh, sw, mul, accumulate);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_bicubic_up_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int scale,
+                                   void* stream) {
+  FFSR_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && scale > 0);
+  hipLaunchKernelGGL(bicubic_up_kernel, dim3(grid_for((long long)B * H * W * scale * scale * C)), dim3(256), 0, ST, in, ldi,
+                     out, ldo, B, H, W, C, scale);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_avgpool2_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, void* stream) {
+  FFSR_CHECK(in && out && B > 0 && H > 1 && W > 1 && C > 0);
+  long long pix = (long long)B * (H / 2) * (W / 2);
+  bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out);
+  if (v4)
+    hipLaunchKernelGGL(avgpool2_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, C);
+  else
+    hipLaunchKernelGGL(avgpool2_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, C);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_u8_to_f32(const unsigned char* in, float* out, int ldo, long long M, int C, void* stream) {
+  FFSR_CHECK(in && out && M > 0 && C > 0 && ldo >= C);
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(M * C)), dim3(256), 0, ST, in, out, ldo, M, C);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_f32_to_u8(const float* in, int ldi, unsigned char* out, long long M, int C, void* stream) {
+  FFSR_CHECK(in && out && M > 0 && C > 0 && ldi >= C);
+  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for(M * C)), dim3(256), 0, ST, in, ldi, out, M, C);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_pad_reflect_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Hp, int Wp, int C,
+                                    void* stream) {
+  FFSR_CHECK(in && out && B > 0 && H > 1 && W > 1 && Hp >= H && Wp >= W && Hp - H < H && Wp - W < W && C > 0);
+  hipLaunchKernelGGL(pad_reflect_kernel, dim3(grid_for((long long)B * Hp * Wp * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H,
+                     W, Hp, Wp, C);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Ho, int Wo, int C,
+                             int do_clamp, void* stream) {
+  FFSR_CHECK(in && out && B > 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W && C > 0);
+  hipLaunchKernelGGL(crop_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, Ho,
+                     Wo, C, do_clamp);
+  return ffsr_launch_status();
+}

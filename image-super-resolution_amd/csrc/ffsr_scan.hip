@@ -1,0 +1,195 @@
+// Mamba selective scan (S6) for the 4-direction SS2D of MambaIR, gfx950.
+//
+//   delta_t = softplus(dt_bias[k,d] + sum_r dtw[k,d,r] * dts_t[k,r])        (dt projection fused in)
+//   h_t[n]  = exp(delta_t * A[k,d,n]) * h_{t-1}[n] + delta_t * B_t[k,n] * u_t[d]
+//   y_t[d]  = sum_n C_t[k,n] * h_t[n] + D[k,d] * u_t[d]
+//
+// Layout (chosen for coalescing, not the reference's [B, K*D, L]): u is pixel-major [L, Dm] so a wave reads 64
+// consecutive channels of one token; the per-token projections xdbl [L, 4*(R+2N)] are wave-uniform.  The four
+// traversals (row-major, column-major and their reverses, mambair_arch.py:343-344) are index maps t -> pixel, so no
+// gathered copy of u is ever materialised, and every direction writes its y back at the pixel it belongs to
+// (the inverse scatter of mambair_arch.py:365-369); the 4 partial outputs are summed by the fused norm/gate kernel.
+//
+// Parallelisation: lane = channel d (16 states in registers); the sequence is cut into chunks:
+//   pass A: per chunk, local end state with h_in = 0 and the chunk's total decay exp(A * sum delta)
+//   pass B: serial carry over chunks (tiny)            pass C: per chunk, recurrence from the true h_in, emits y.
+#include "ffsr_common.h"
+
+namespace {
+
+constexpr int NS = 16;  // d_state
+
+struct ScanArgs {
+  const float* u;     // [B, L, ldu]
+  const float* xdbl;  // [B, L, ldx]
+  const float* dtw;   // [4, Dm, R]
+  const float* dtb;   // [4, Dm]
+  const float* A;     // [4, Dm, NS]
+  const float* Dv;    // [4, Dm]
+  float* y;           // [4, B, L, ldy]
+  float* hstate;      // [B, 4, nchunk, Dm, NS]  local end state (pass A) -> incoming state (pass B)
+  float* decay;       // [B, 4, nchunk, Dm, NS]
+  int B, H, W, L, Dm, ldu, ldx, ldy, R, chunk, nchunk;
+};
+
+__device__ __forceinline__ int tok_pixel(int k, int t, int H, int W, int L) {
+  if (k & 2) t = L - 1 - t;
+  if (k & 1) {
+    int x = t / H, yy = t - x * H;
+    return yy * W + x;
+  }
+  return t;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+template <int R, bool EMIT>
+__global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs p) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int k = blockIdx.z & 3, b = blockIdx.z >> 2;
+  const bool live = d < p.Dm;
+  const int dd = live ? d : p.Dm - 1;
+  float w[R], a[NS], h[NS];
+#pragma unroll
+  for (int r = 0; r < R; ++r) w[r] = p.dtw[((size_t)k * p.Dm + dd) * R + r];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) a[n] = p.A[((size_t)k * p.Dm + dd) * NS + n];
+  const float bias = p.dtb[k * p.Dm + dd];
+  const float dskip = p.Dv[k * p.Dm + dd];
+  const size_t sidx = ((((size_t)b * 4 + k) * p.nchunk + c) * p.Dm + dd) * NS;
+#pragma unroll
+  for (int n = 0; n < NS; ++n) h[n] = EMIT ? p.hstate[sidx + n] : 0.f;
+  float dsum = 0.f;
+  const int t0 = c * p.chunk, t1 = min(p.L, t0 + p.chunk);
+  const float* ub = p.u + (size_t)b * p.L * p.ldu;
+  const float* xb = p.xdbl + (size_t)b * p.L * p.ldx + k * (R + 2 * NS);
+  float* yb = p.y + ((size_t)k * p.B + b) * p.L * p.ldy;
+  for (int t = t0; t < t1; ++t) {
+    const int pix = tok_pixel(k, t, p.H, p.W, p.L);
+    const float* xr = xb + (size_t)pix * p.ldx;  // wave-uniform row
+    const float uu = ub[(size_t)pix * p.ldu + dd];
+    float dt = bias;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dt = fmaf(w[r], xr[r], dt);
+    const float delta = softplus_f(dt);
+    const float du = delta * uu;
+    float yv = 0.f;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      const float dA = expf(delta * a[n]);
+      h[n] = fmaf(dA, h[n], du * xr[R + n]);
+      if (EMIT) yv = fmaf(xr[R + NS + n], h[n], yv);
+    }
+    if (EMIT) {
+      if (live) yb[(size_t)pix * p.ldy + d] = fmaf(dskip, uu, yv);
+    } else {
+      dsum += delta;
+    }
+  }
+  if (!EMIT && live) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      p.hstate[sidx + n] = h[n];
+      p.decay[sidx + n] = expf(a[n] * dsum);
+    }
+  }
+}
+
+// hstate[c] <- state entering chunk c
+__global__ void scan_carry_kernel(float* __restrict__ hstate, const float* __restrict__ decay, int groups, int nchunk,
+                                  int per) {
+  // groups = B*4, per = Dm*NS
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= groups * per) return;
+  int g = idx / per, i = idx - g * per;
+  float hin = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    size_t o = ((size_t)g * nchunk + c) * per + i;
+    float hl = hstate[o], dc = decay[o];
+    hstate[o] = hin;
+    hin = fmaf(dc, hin, hl);
+  }
+}
+
+// y = LayerNorm_Dm(y0 + y1 + y2 + y3) * silu(z)        (SS2D.forward, mambair_arch.py:380-384)
+__global__ __launch_bounds__(256) void mamba_norm_gate_kernel(const float* __restrict__ y, size_t ystride, int ldy,
+                                                              const float* __restrict__ z, int ldz,
+                                                              const float* __restrict__ g, const float* __restrict__ be,
+                                                              float eps, float* __restrict__ out, int ldo, int M, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < C) {
+      const float* p0 = y + (size_t)row * ldy + c;
+      t = ((p0[0] + p0[2 * ystride]) + p0[ystride]) + p0[3 * ystride];  // y1+y2+y3+y4 order of mambair_arch.py:381
+    }
+    v[i] = t;
+    s += t;
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float dlt = (lane + 64 * i < C) ? v[i] - mean : 0.f;
+    q += dlt * dlt;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int c = lane + 64 * i;
+    if (c < C) {
+      float zz = z[(size_t)row * ldz + c];
+      float yn = (v[i] - mean) * rstd * g[c] + be[c];
+      out[(size_t)row * ldo + c] = yn * (zz / (1.0f + expf(-zz)));
+    }
+  }
+}
+
+template <int R>
+int run_scan(const ScanArgs& a, hipStream_t st) {
+  dim3 grid((a.Dm + 63) / 64, a.nchunk, 4 * a.B);
+  hipLaunchKernelGGL((scan_chunk_kernel<R, false>), grid, dim3(64), 0, st, a);
+  int tot = a.B * 4 * a.Dm * NS;
+  hipLaunchKernelGGL(scan_carry_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, a.hstate, a.decay, a.B * 4, a.nchunk,
+                     a.Dm * NS);
+  hipLaunchKernelGGL((scan_chunk_kernel<R, true>), grid, dim3(64), 0, st, a);
+  return ffsr_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw,
+                                        const float* dtb, const float* A, const float* Dv, float* y, int ldy,
+                                        float* hstate, float* decay, int B, int H, int W, int Dm, int R, int d_state,
+                                        int chunk, void* stream) {
+  FFSR_CHECK(u && xdbl && dtw && dtb && A && Dv && y && hstate && decay);
+  FFSR_CHECK(B > 0 && H > 0 && W > 0 && Dm > 0 && d_state == NS && chunk > 0);
+  FFSR_CHECK(ldu >= Dm && ldy >= Dm && ldx >= 4 * (R + 2 * NS));
+  ScanArgs a;
+  a.u = u; a.xdbl = xdbl; a.dtw = dtw; a.dtb = dtb; a.A = A; a.Dv = Dv; a.y = y; a.hstate = hstate; a.decay = decay;
+  a.B = B; a.H = H; a.W = W; a.L = H * W; a.Dm = Dm; a.ldu = ldu; a.ldx = ldx; a.ldy = ldy; a.R = R; a.chunk = chunk;
+  a.nchunk = (a.L + chunk - 1) / chunk;
+  FFSR_CHECK(a.nchunk <= 65535 && 4 * B <= 65535);
+  hipStream_t st = (hipStream_t)stream;
+  switch (R) {
+    case 12: return run_scan<12>(a, st);
+    case 3: return run_scan<3>(a, st);
+    default: return FFSR_EINVAL;
+  }
+}
+
+extern "C" int ffsr_mamba_norm_gate_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
+                                        const float* gamma, const float* beta, float eps, float* out, int ldo, int M, int C,
+                                        void* stream) {
+  FFSR_CHECK(y && z && gamma && beta && out && M > 0 && C > 0 && C <= 512);
+  hipLaunchKernelGGL(mamba_norm_gate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, (size_t)ystride, ldy, z,
+                     ldz, gamma, beta, eps, out, ldo, M, C);
+  return ffsr_launch_status();
+}

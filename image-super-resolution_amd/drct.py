@@ -1,0 +1,87 @@
+"""DRCT-L x4 on the HIP kernels (host side).  Mirrors src/models/drct/drct_arch.py: DRCT.forward :777,
+forward_features :761, RDG.forward :292 (dense concat kept in ONE [pixels, 308] buffer, every block writes its
+32 new channels in place), SwinTransformerBlock.forward :376 (roll / partition / mask folded into the
+attention kernel's addressing), WindowAttention.forward :175.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .common import SRTail, dev, to_map, tokens
+from .ops import ACT_GELU, ACT_LRELU
+
+
+def _rel_index(ws):
+    c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
+    return (rel[..., 0] * (2 * ws - 1) + rel[..., 1]).reshape(-1)
+
+
+class _Swin:
+    def __init__(self, sd, p, device, dim, heads, ws, shift):
+        self.dim, self.heads, self.ws, self.shift = dim, heads, ws, shift
+        self.n1 = (dev(sd[p + "norm1.weight"], device), dev(sd[p + "norm1.bias"], device))
+        self.n2 = (dev(sd[p + "norm2.weight"], device), dev(sd[p + "norm2.bias"], device))
+        self.qkv = ops.pack_conv(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], device)
+        self.proj = ops.pack_conv(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], device)
+        self.fc1 = ops.pack_conv(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], device)
+        self.fc2 = ops.pack_conv(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], device)
+        N = ws * ws
+        table = sd[p + "attn.relative_position_bias_table"].float()
+        self.bias = dev(table[_rel_index(ws)].reshape(N, N, heads).permute(2, 0, 1), device)   # [heads, N, N]
+        self.scale = (dim // heads) ** -0.5
+
+    def __call__(self, x, B, H, W):
+        """x [P, dim] (row stride may be wider) -> [P, dim]"""
+        n = ops.layernorm(x, *self.n1)
+        qkv = ops.linear(n, self.qkv)
+        a = ops.window_attn(qkv, self.bias, B, H, W, self.dim, self.heads, self.ws, self.shift, self.scale)
+        y = ops.linear(a, self.proj, res=x)
+        h = ops.linear(ops.layernorm(y, *self.n2), self.fc1, act=ACT_GELU)
+        return ops.linear(h, self.fc2, res=y)
+
+
+class DRCT:
+    def __init__(self, sd, device, ws=16, heads=6, gc=32):
+        self.device, self.ws, self.gc = device, ws, gc
+        self.embed = sd["conv_first.weight"].shape[0]
+        n_groups = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("layers."))
+        self.conv_first = ops.pack_conv(sd["conv_first.weight"], sd["conv_first.bias"], device)
+        self.pe_norm = (dev(sd["patch_embed.norm.weight"], device), dev(sd["patch_embed.norm.bias"], device))
+        self.norm = (dev(sd["norm.weight"], device), dev(sd["norm.bias"], device))
+        self.groups = []
+        for i in range(n_groups):
+            blocks = []
+            for j in range(5):
+                dim = self.embed + gc * j
+                h = heads if j == 0 else heads - (dim % heads)
+                sw = _Swin(sd, f"layers.{i}.swin{j + 1}.", device, dim, h, ws, ws // 2 if j % 2 else 0)
+                adj = ops.pack_conv(sd[f"layers.{i}.adjust{j + 1}.weight"], sd[f"layers.{i}.adjust{j + 1}.bias"], device)
+                blocks.append((sw, adj))
+            self.groups.append(blocks)
+        self.tail = SRTail(sd, device)
+
+    def __call__(self, lr):
+        """lr [B,H,W,3] (H, W multiples of the window) -> (sr [B,4H,4W,3] un-clamped, feat [B,H,W,embed])."""
+        B, H, W, _ = lr.shape
+        if H % self.ws or W % self.ws:
+            raise ValueError(f"DRCT input {H}x{W} must be a multiple of the window size {self.ws}")
+        E, gc, P = self.embed, self.gc, B * H * W
+        x0 = ops.conv2d(self.tail.center(lr), self.conv_first)
+        wide = E + 4 * gc
+        cat = [torch.empty(P, wide, device=lr.device), torch.empty(P, wide, device=lr.device)]
+        ops.layernorm(tokens(x0), *self.pe_norm, out=cat[0][:, :E])
+        cur = 0
+        for blocks in self.groups:
+            buf = cat[cur]
+            for j, (sw, adj) in enumerate(blocks):
+                dim = E + gc * j
+                y = sw(buf[:, :dim], B, H, W)
+                if j < 4:
+                    ops.linear(y, adj, act=ACT_LRELU, slope=0.2, out=buf[:, dim:dim + gc])
+                else:
+                    ops.linear(y, adj, cscale=0.2, res=buf[:, :E], out=cat[1 - cur][:, :E])     # x5 * 0.2 + x
+            cur = 1 - cur
+        t = ops.layernorm(cat[cur][:, :E], *self.norm)
+        return self.tail(to_map(t, B, H, W), x0)

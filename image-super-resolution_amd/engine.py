@@ -1,0 +1,94 @@
+"""Per-image pipeline of the NTIRE entry point on the HIP engine.
+
+Host-side mirror of models/team29_FreqFusionSR/io.py: ``Engine.__init__`` = _load_all_models :126 (weights
+resident on the device, packed once), ``Engine.process`` = _process_image :222 (pad16 -> DRCT -> GRL ->
+NAFNet -> MambaIR -> crops / clamps -> fusion.forward_with_precomputed).  Differences that do not change
+results: no per-image mask/table rebuilds or H2D copies, no empty_cache().
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import ops
+from .drct import DRCT
+from .fusion import EXPERTS, FusionNet
+from .grl import GRL
+from .mambair import MambaIR
+from .nafnet import NAFNetSR
+
+
+def require_gpu(device) -> torch.device:
+    device = torch.device(device if device is not None else "cuda")
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("the FreqFusionSR HIP engine needs an MI355X (ROCm) device; there is no CPU fallback")
+    return device
+
+
+class Engine:
+    def __init__(self, weights: Dict[str, dict], device=None, scale=4):
+        self.device = require_gpu(device)
+        self.scale = scale
+        with torch.cuda.device(self.device):
+            self.drct = DRCT(weights["drct"], self.device)
+            self.grl = GRL(weights["grl"], self.device)
+            self.nafnet = NAFNetSR(weights["nafnet"], self.device, scale)
+            self.mamba = MambaIR(weights["mamba"], self.device)
+            self.fusion = FusionNet(weights["fusion"], self.device, scale)
+
+    # -------------------------------------------------------------------------------------- experts
+    def run_experts(self, lr):
+        """lr [B,h,w,3] float map -> (imgs, feats) as io._process_image builds them (io.py:224-278)."""
+        B, h, w, _ = lr.shape
+        s = self.scale
+        hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+        lp = ops.pad_reflect(lr, hp, wp)
+        imgs, feats = {}, {}
+        for name, model in (("drct", self.drct), ("grl", self.grl)):
+            sr, f = model(lp)
+            imgs[name] = ops.crop(sr, h * s, w * s, clamp=True)
+            feats[name] = ops.crop(f, h, w)
+            del sr, f
+        sr, f = self.nafnet(lp)
+        imgs["nafnet"] = ops.crop(sr, h * s, w * s)
+        feats["nafnet"] = ops.bilinear(f, h, w)          # padded HR map straight to (h, w): io.py:256-258
+        del sr, f
+        sr, f = self.mamba(lp)
+        imgs["mamba"] = ops.crop(sr, h * s, w * s, clamp=True)
+        feats["mamba"] = ops.crop(f, h, w)
+        return imgs, feats
+
+    def process(self, lr):
+        """lr [B,h,w,3] float map in [0,1] -> SR map [B,4h,4w,3] in [0,1]."""
+        with torch.cuda.device(self.device):
+            imgs, feats = self.run_experts(lr)
+            return self.fusion(lr, imgs, feats)
+
+    # -------------------------------------------------------------------------------------- uint8 boundary
+    def upload(self, img_u8: np.ndarray) -> torch.Tensor:
+        """uint8 HxWx3 RGB (host) -> float map [1,h,w,3] on the device (io._uint2tensor4)."""
+        t = torch.from_numpy(np.ascontiguousarray(img_u8)).to(self.device, non_blocking=True)
+        return ops.u8_to_map(t.unsqueeze(0))
+
+    def download(self, sr) -> np.ndarray:
+        """SR map [1,H,W,3] -> uint8 HxWx3 (io._tensor2uint: clamp, *255, round half to even)."""
+        return ops.map_to_u8(sr)[0].cpu().numpy()
+
+    def process_u8(self, img_u8: np.ndarray) -> np.ndarray:
+        with torch.cuda.device(self.device):
+            return self.download(self.process(self.upload(img_u8)))
+
+
+# ---------------------------------------------------------------------------------------------- layout helpers
+def nchw_to_map(x: torch.Tensor, device) -> torch.Tensor:
+    """[B,C,H,W] (any device) -> channels-last map on `device` with the stride padded to a multiple of 4."""
+    B, C, H, W = x.shape
+    m = ops.new_map(B, H, W, C, device)
+    m.copy_(x.to(device).permute(0, 2, 3, 1))
+    return m
+
+
+def map_to_nchw(m: torch.Tensor) -> torch.Tensor:
+    return m.permute(0, 3, 1, 2).contiguous().cpu()

@@ -1,0 +1,86 @@
+"""NAFNet-SIDD-width64 as an x4 SR expert on the HIP kernels (host side).
+
+Mirrors src/models/nafnet/__init__.py:NAFNetSR.forward :117 (bicubic x4 -> U-Net at HR -> clamp) and
+nafnet_arch.py (NAFBlock.forward :110, NAFNet.forward :195).  ``sd`` = the inner NAFNet state_dict
+(official checkpoint keys).  Returns the SR image and the feature entering ``ending`` (the tensor the
+reference's forward hook captures, expert_loader.py:553-558).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .common import dev
+
+
+class _Block:
+    def __init__(self, sd, p, device):
+        c = sd[p + "conv3.weight"].shape[0]
+        self.c = c
+        self.n1 = (dev(sd[p + "norm1.weight"], device), dev(sd[p + "norm1.bias"], device))
+        self.n2 = (dev(sd[p + "norm2.weight"], device), dev(sd[p + "norm2.bias"], device))
+        self.conv1 = ops.pack_conv(sd[p + "conv1.weight"], sd[p + "conv1.bias"], device)
+        self.dw = ops.pack_dwconv(sd[p + "conv2.weight"], sd[p + "conv2.bias"], device)
+        self.conv3 = ops.pack_conv(sd[p + "conv3.weight"], sd[p + "conv3.bias"], device)
+        self.sca = ops.pack_conv(sd[p + "sca.1.weight"], sd[p + "sca.1.bias"], device)
+        self.conv4 = ops.pack_conv(sd[p + "conv4.weight"], sd[p + "conv4.bias"], device)
+        self.conv5 = ops.pack_conv(sd[p + "conv5.weight"], sd[p + "conv5.bias"], device)
+        self.beta = dev(sd[p + "beta"].reshape(-1), device)
+        self.gamma = dev(sd[p + "gamma"].reshape(-1), device)
+
+    def __call__(self, x):
+        c = self.c
+        t = ops.layernorm(x, *self.n1, eps=1e-6)
+        t = ops.conv2d(t, self.conv1)
+        g, pooled = ops.dw3x3_gate_pool(t, self.dw)              # SimpleGate + global average pool
+        sca = ops.linear(pooled, self.sca)                       # [B, c] channel attention
+        y = ops.conv2d(g, self.conv3, akscale=sca.contiguous(), res=x, cvec=self.beta)   # x + conv3(g*sca)*beta
+        t = ops.conv2d(ops.layernorm(y, *self.n2, eps=1e-6), self.conv4)
+        g = ops.mul_add(t[..., :c], t[..., c:])                  # SimpleGate
+        return ops.conv2d(g, self.conv5, res=y, cvec=self.gamma)
+
+
+class NAFNetSR:
+    def __init__(self, sd, device, scale=4):
+        self.scale = scale
+        self.device = device
+        n_enc = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("encoders."))
+        n_dec = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("decoders."))
+
+        def blocks(prefix):
+            idx = sorted({int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix)})
+            return [_Block(sd, f"{prefix}{j}.", device) for j in idx]
+
+        self.intro = ops.pack_conv(sd["intro.weight"], sd["intro.bias"], device)
+        self.ending = ops.pack_conv(sd["ending.weight"], sd["ending.bias"], device)
+        self.enc = [blocks(f"encoders.{i}.") for i in range(n_enc)]
+        self.downs = [ops.pack_conv(sd[f"downs.{i}.weight"], sd[f"downs.{i}.bias"], device, stride=2, pad=0)
+                      for i in range(n_enc)]
+        self.mid = blocks("middle_blks.")
+        self.ups = [ops.pack_conv(sd[f"ups.{i}.0.weight"], None, device) for i in range(n_dec)]
+        self.dec = [blocks(f"decoders.{i}.") for i in range(n_dec)]
+        self.mult = 2 ** n_enc
+
+    def __call__(self, lr):
+        """lr [B,h,w,3] (ld 4) -> (sr [B,4h,4w,3] clamped to [0,1], feat [B,4h,4w,width])."""
+        B, h, w, _ = lr.shape
+        H, W = h * self.scale, w * self.scale
+        if H % self.mult or W % self.mult:
+            raise ValueError(f"NAFNet input {H}x{W} must be a multiple of {self.mult} (io.main pads LR to 16)")
+        up = ops.bicubic_up(lr, self.scale)
+        x = ops.conv2d(up, self.intro)
+        skips = []
+        for blks, down in zip(self.enc, self.downs):
+            for blk in blks:
+                x = blk(x)
+            skips.append(x)
+            x = ops.conv2d(x, down)
+        for blk in self.mid:
+            x = blk(x)
+        for blks, upc, skip in zip(self.dec, self.ups, reversed(skips)):
+            x = ops.conv2d(x, upc, shuffle=2, res=skip)           # 1x1 conv + PixelShuffle(2) + skip
+            for blk in blks:
+                x = blk(x)
+        feat = x
+        out = ops.conv2d(x, self.ending, res=up)
+        return ops.unary(out, clamp=(0.0, 1.0), out=out), feat

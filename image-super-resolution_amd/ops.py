@@ -1,0 +1,429 @@
+"""Launch helpers: channels-last torch tensors in, HIP kernels through the C ABI, torch tensors out.
+
+torch is used for device memory (allocation, views) and the current stream only; every arithmetic
+operation goes through libffsr_hip.so.  A feature map is a tensor of shape [B, H, W, C] whose last
+dimension is contiguous and whose pixel stride ("ld") may exceed C (channel slices of a wider buffer,
+or channels padded to a multiple of 4).  Token matrices [M, C] are maps with B = H = 1.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import hip
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SILU = range(6)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def ld(t: torch.Tensor) -> int:
+    """Pixel stride of a channels-last map; validates the layout contract."""
+    assert t.dtype == torch.float32 and t.is_cuda, "ffsr ops need fp32 device tensors"
+    assert t.dim() == 4 and t.stride(3) == 1, f"not channels-last: {t.shape} {t.stride()}"
+    B, H, W, C = t.shape
+    s = t.stride(2)
+    if s < C:                      # degenerate stride of a size-1 dimension
+        assert W == 1, f"bad pixel stride: {t.shape} {t.stride()}"
+        s = t.stride(1) if (H > 1 and t.stride(1) >= C) else (t.stride(0) if (B > 1 and t.stride(0) >= C) else C)
+    if W > 1 and H > 1:
+        assert t.stride(1) == W * s, f"rows not dense: {t.shape} {t.stride()}"
+    if B > 1 and (H > 1 or W > 1):
+        assert t.stride(0) == H * W * s, f"batches not dense: {t.shape} {t.stride()}"
+    return s
+
+
+def new_map(B, H, W, C, device, zero_pad=True) -> torch.Tensor:
+    """[B,H,W,C] view of a buffer whose pixel stride is padded to a multiple of 4 (pad channels zeroed)."""
+    Cp = pad4(C)
+    if Cp == C:
+        return torch.empty(B, H, W, C, device=device, dtype=torch.float32)
+    buf = (torch.zeros if zero_pad else torch.empty)(B, H, W, Cp, device=device, dtype=torch.float32)
+    return buf[..., :C]
+
+
+def widen(t: torch.Tensor, C: int) -> torch.Tensor:
+    """View of the same pixels with C channels (C <= ld): exposes the zero padding to a consumer."""
+    s = ld(t)
+    assert C <= s
+    B, H, W, _ = t.shape
+    return t.as_strided((B, H, W, C), (H * W * s, W * s, s, 1), t.storage_offset())
+
+
+def as_map(x2d: torch.Tensor) -> torch.Tensor:
+    """[M, C] (row stride ld) -> [1, 1, M, C] map."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    return x2d.as_strided((1, 1, x2d.shape[0], x2d.shape[1]), (0, 0, x2d.stride(0), 1), x2d.storage_offset())
+
+
+def rows(t: torch.Tensor) -> int:
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+# ---------------------------------------------------------------------------------------------- packed weights
+@dataclass
+class Conv:
+    """A conv / linear layer packed for ffsr_conv2d_f32: wgt [N, KH*KW*Cin_pad] tap-major, channel-minor."""
+    wgt: torch.Tensor
+    bias: Optional[torch.Tensor]
+    N: int
+    Cin: int       # padded input channels the kernel contracts over
+    KH: int = 1
+    KW: int = 1
+    stride: int = 1
+    pad: int = 0
+
+
+def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
+              in_perm=None) -> Conv:
+    """w: [N, Cin, KH, KW] (nn.Conv2d) or [N, K] (nn.Linear).  cin_pad: padded channel count of the input map."""
+    w = w.detach().float()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    N, Cin, KH, KW = w.shape
+    Cp = cin_pad if cin_pad is not None else pad4(Cin)
+    assert Cp >= Cin and Cp % 4 == 0
+    wp = torch.zeros(N, KH, KW, Cp, dtype=torch.float32)
+    wp[..., :Cin] = w.permute(0, 2, 3, 1)
+    if pad is None:
+        pad = KH // 2
+    return Conv(wp.reshape(N, KH * KW * Cp).contiguous().to(device),
+                None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride, pad)
+
+
+def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
+           res: Optional[torch.Tensor] = None, cvec=None, rvec=None, cscale=1.0, rscale=1.0, shuffle=0,
+           akscale: Optional[torch.Tensor] = None, tile_hint=0) -> torch.Tensor:
+    """x [B,H,W,>=Cin] -> [B,Ho,Wo,N] (or [B,2Ho,2Wo,N/4] with shuffle=2)."""
+    B, H, W, _ = x.shape
+    ldi = ld(x)
+    assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"
+    Ho = (H + 2 * cv.pad - cv.KH) // cv.stride + 1
+    Wo = (W + 2 * cv.pad - cv.KW) // cv.stride + 1
+    if shuffle:
+        oshape = (B, 2 * Ho, 2 * Wo, cv.N // 4)
+    else:
+        oshape = (B, Ho, Wo, cv.N)
+    if out is None:
+        out = new_map(*oshape, x.device)
+    assert tuple(out.shape) == oshape, f"{tuple(out.shape)} != {oshape}"
+    ldr = 0
+    if res is not None:
+        assert tuple(res.shape) == oshape
+        ldr = ld(res)
+    akrows = 0
+    if akscale is not None:
+        assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
+        akrows = H * W
+    hip.call("ffsr_conv2d_f32", _ptr(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
+             _ptr(akscale), B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad,
+             act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+    return out
+
+
+def linear(x2d: torch.Tensor, cv: Conv, **kw) -> torch.Tensor:
+    """x2d [M, K] -> [M, N]; keyword tensors (out / res) are [M, *] matrices too."""
+    for k in ("out", "res"):
+        if kw.get(k) is not None:
+            kw[k] = as_map(kw[k])
+    y = conv2d(as_map(x2d), cv, **kw)
+    return y.as_strided((y.shape[2], y.shape[3]), (ld(y), 1), y.storage_offset())
+
+
+# ---------------------------------------------------------------------------------------------- row kernels
+def _mat(t: torch.Tensor):
+    """(tensor, M, C, ld) for a map or a 2-D matrix."""
+    if t.dim() == 2:
+        assert t.stride(1) == 1
+        return t, t.shape[0], t.shape[1], (t.stride(0) if t.stride(0) >= t.shape[1] else t.shape[1])
+    return t, rows(t), t.shape[3], ld(t)
+
+
+def _like(t: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
+    if t.dim() == 2:
+        C = C or t.shape[1]
+        Cp = pad4(C)
+        buf = torch.zeros(t.shape[0], Cp, device=t.device) if Cp != C else torch.empty(t.shape[0], C, device=t.device)
+        return buf[:, :C]
+    return new_map(t.shape[0], t.shape[1], t.shape[2], C or t.shape[3], t.device)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None):
+    _, M, C, ldx = _mat(x)
+    if out is None:
+        out = _like(x)
+    r1 = _mat(res1) if res1 is not None else (None, 0, 0, 0)
+    r2 = _mat(res2) if res2 is not None else (None, 0, 0, 0)
+    hip.call("ffsr_layernorm_f32", _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _mat(out)[3],
+             _ptr(r1[0]), r1[3], _ptr(r2[0]), r2[3], M, C, _stream())
+    return out
+
+
+def unary(x, act=ACT_NONE, slope=0.0, pre=1.0, alpha=1.0, beta=0.0, cscale=None, cbias=None, clamp=None, out=None):
+    _, M, C, ldx = _mat(x)
+    if out is None:
+        out = _like(x)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    hip.call("ffsr_unary_f32", _ptr(x), ldx, _ptr(out), _mat(out)[3], M, C, act, float(slope), float(pre),
+             float(alpha), float(beta), _ptr(cscale), _ptr(cbias), int(clamp is not None), float(lo), float(hi), _stream())
+    return out
+
+
+def scale_add(a, b=None, *, avec=None, bvec=None, rows_per_batch=None, alpha=1.0, beta=1.0, out=None):
+    """out = alpha * a * avec[n] + beta * b * bvec[batch, n]"""
+    _, M, C, lda = _mat(a)
+    if out is None:
+        out = _like(a)
+    ldb = _mat(b)[3] if b is not None else 0
+    if rows_per_batch is None:
+        rows_per_batch = M if a.dim() == 2 else a.shape[1] * a.shape[2]
+    hip.call("ffsr_scale_add_f32", _ptr(a), lda, _ptr(avec), _ptr(b), ldb, _ptr(bvec), rows_per_batch, _ptr(out),
+             _mat(out)[3], M, C, float(alpha), float(beta), _stream())
+    return out
+
+
+def mul_add(a, b, *, row_broadcast=False, c=None, alpha=1.0, gamma=1.0, out=None):
+    """out = alpha * a * b (+ gamma * c); row_broadcast: b has one channel per pixel."""
+    _, M, C, lda = _mat(a)
+    if out is None:
+        out = _like(a)
+    ldc = _mat(c)[3] if c is not None else 0
+    hip.call("ffsr_mul_add_f32", _ptr(a), lda, _ptr(b), _mat(b)[3], int(row_broadcast), _ptr(c), ldc, _ptr(out),
+             _mat(out)[3], M, C, float(alpha), float(gamma), _stream())
+    return out
+
+
+def _nchunk(R: int) -> int:
+    return max(1, min(1024, R // 256))
+
+
+def colmean(x: torch.Tensor) -> torch.Tensor:
+    """[B,H,W,C] -> [B,C] spatial mean."""
+    B, H, W, C = x.shape
+    n = _nchunk(H * W)
+    part = torch.empty(B, n, C, device=x.device)
+    out = torch.empty(B, C, device=x.device)
+    hip.call("ffsr_colmean_f32", _ptr(x), ld(x), _ptr(out), _ptr(part), B, H * W, C, n, _stream())
+    return out
+
+
+@dataclass
+class DwConv:
+    w: torch.Tensor           # [KH*KW, C]
+    bias: Optional[torch.Tensor]
+    KH: int
+    KW: int
+    ph: int
+    pw: int
+
+
+def pack_dwconv(w: torch.Tensor, b, device, pad=None) -> DwConv:
+    C, one, KH, KW = w.shape
+    assert one == 1
+    ph, pw = (KH // 2, KW // 2) if pad is None else pad
+    return DwConv(w.detach().float().reshape(C, KH * KW).t().contiguous().to(device),
+                  None if b is None else b.detach().float().contiguous().to(device), KH, KW, ph, pw)
+
+
+def dwconv2d(x, dw: DwConv, act=ACT_NONE, out=None):
+    B, H, W, C = x.shape
+    if out is None:
+        out = _like(x)
+    hip.call("ffsr_dwconv2d_f32", _ptr(x), ld(x), _ptr(dw.w), _ptr(dw.bias), _ptr(out), ld(out), B, H, W, C, dw.KH,
+             dw.KW, dw.ph, dw.pw, act, _stream())
+    return out
+
+
+def dw3x3_gate_pool(x, dw: DwConv):
+    """x [B,H,W,2C] -> (gated [B,H,W,C], pooled mean [B,C])"""
+    B, H, W, C2 = x.shape
+    C = C2 // 2
+    out = new_map(B, H, W, C, x.device)
+    n = _nchunk(H * W)
+    part = torch.empty(B, n, C, device=x.device)
+    pooled = torch.empty(B, C, device=x.device)
+    hip.call("ffsr_dw3x3_gate_pool_f32", _ptr(x), ld(x), _ptr(dw.w), _ptr(dw.bias), _ptr(out), ld(out), _ptr(pooled),
+             _ptr(part), B, H, W, C, n, _stream())
+    return out, pooled
+
+
+def bilinear(x, Ho, Wo, mul=1.0, out=None, accumulate=False):
+    B, Hi, Wi, C = x.shape
+    if out is None:
+        out = new_map(B, Ho, Wo, C, x.device)
+    hip.call("ffsr_bilinear_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, Hi, Wi, Ho, Wo, C, float(mul),
+             int(accumulate), _stream())
+    return out
+
+
+def bicubic_up(x, scale=4, out=None):
+    B, H, W, C = x.shape
+    if out is None:
+        out = new_map(B, H * scale, W * scale, C, x.device)
+    hip.call("ffsr_bicubic_up_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, H, W, C, scale, _stream())
+    return out
+
+
+def avgpool2(x, out=None):
+    B, H, W, C = x.shape
+    if out is None:
+        out = new_map(B, H // 2, W // 2, C, x.device)
+    hip.call("ffsr_avgpool2_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, H, W, C, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- attention / scan
+def window_attn(qkv, bias, B, H, W, C, heads, ws, shift, scale, out=None):
+    """qkv [B*H*W, 3C] -> [B*H*W, C]"""
+    if out is None:
+        out = torch.empty(B * H * W, C, device=qkv.device)
+    hip.call("ffsr_window_attn_f32", _ptr(qkv), _mat(qkv)[3], _ptr(bias), _ptr(out), _mat(out)[3], B, H, W, C, heads,
+             ws, shift, float(scale), _stream())
+    return out
+
+
+def grl_window_attn(qkv, col0, biasT, logit, out, ocol0, B, H, W, heads, hd, shift):
+    hip.call("ffsr_grl_window_attn_f32", _ptr(qkv), _mat(qkv)[3], col0, _ptr(biasT), _ptr(logit), _ptr(out),
+             _mat(out)[3], ocol0, B, H, W, heads, hd, shift, _stream())
+    return out
+
+
+def grl_stripe_attn(qkv, col0, anchor, bias1T, bias2T, logit1, logit2, out, ocol0, B, H, W, heads, hd):
+    hip.call("ffsr_grl_stripe_attn_f32", _ptr(qkv), _mat(qkv)[3], col0, _ptr(anchor), ld(anchor), _ptr(bias1T),
+             _ptr(bias2T), _ptr(logit1), _ptr(logit2), _ptr(out), _mat(out)[3], ocol0, B, H, W, heads, hd, _stream())
+    return out
+
+
+def pixel_mha(qkv, S, T, E, heads, out=None):
+    if out is None:
+        out = torch.empty(S * T, E, device=qkv.device)
+    hip.call("ffsr_pixel_mha_f32", _ptr(qkv), _mat(qkv)[3], _ptr(out), _mat(out)[3], S, T, E, heads, _stream())
+    return out
+
+
+def scan_chunk(L: int) -> int:
+    """Chunk length of the 3-pass scan: enough chunks to fill 256 CUs, at least 32 steps each."""
+    return int(min(1024, max(32, 2 ** math.ceil(math.log2(max(1, L / 256))))))
+
+
+def selective_scan4(u, xdbl, dtw, dtb, A, Dv, B, H, W, Dm, R, chunk=None):
+    """u [B*L, Dm], xdbl [B*L, 4*(R+32)] -> y [4, B*L, Dm] (per-direction outputs in pixel order)."""
+    L = H * W
+    chunk = chunk or scan_chunk(L)
+    nchunk = (L + chunk - 1) // chunk
+    y = torch.empty(4, B * L, Dm, device=u.device)
+    hstate = torch.empty(B, 4, nchunk, Dm, 16, device=u.device)
+    decay = torch.empty_like(hstate)
+    hip.call("ffsr_selective_scan4_f32", _ptr(u), _mat(u)[3], _ptr(xdbl), _mat(xdbl)[3], _ptr(dtw), _ptr(dtb), _ptr(A),
+             _ptr(Dv), _ptr(y), Dm, _ptr(hstate), _ptr(decay), B, H, W, Dm, R, 16, chunk, _stream())
+    return y
+
+
+def mamba_norm_gate(y4, z, gamma, beta, eps=1e-5, out=None):
+    """y4 [4, M, C], z [M, C] (row stride ldz) -> LayerNorm(sum_k y4[k]) * silu(z)"""
+    _, M, C = y4.shape
+    if out is None:
+        out = torch.empty(M, C, device=y4.device)
+    hip.call("ffsr_mamba_norm_gate_f32", _ptr(y4), M * C, C, _ptr(z), _mat(z)[3], _ptr(gamma), _ptr(beta), float(eps),
+             _ptr(out), _mat(out)[3], M, C, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- fusion specials
+def dct_bands(img, D, masks, scale, bands):
+    B, H, W, _ = img.shape
+    hip.call("ffsr_dct_bands_f32", _ptr(img), ld(img), _ptr(D), _ptr(masks), _ptr(scale), _ptr(bands), 36, B, H, W,
+             _stream())
+
+
+def dwt_db4(img, lo, hi):
+    B, H, W, _ = img.shape
+    Hd, Wd = (H + 6) // 2 + 1, (W + 6) // 2 + 1
+    sub = torch.zeros(B, Hd, Wd, 16, device=img.device)
+    hip.call("ffsr_dwt_db4_f32", _ptr(img), ld(img), _ptr(lo), _ptr(hi), _ptr(sub), B, H, W, _stream())
+    return sub
+
+
+def fft_bands(img, twW, twH, mask, scale, bands):
+    B, H, W, _ = img.shape
+    work = torch.empty(10 * B * 3 * H * (W // 2 + 1), device=img.device)
+    hip.call("ffsr_fft_bands_f32", _ptr(img), ld(img), _ptr(twW), _ptr(twH), _ptr(mask), _ptr(scale), _ptr(work),
+             _ptr(bands), 36, B, H, W, _stream())
+
+
+def selector_gates(raw, diff, temperature):
+    B, h, w, _ = raw.shape
+    gates = torch.empty(B, h, w, 4, device=raw.device)
+    hip.call("ffsr_selector_gates_f32", _ptr(raw), ld(raw), _ptr(diff), ld(diff), _ptr(temperature), _ptr(gates), 4,
+             B * h * w, _stream())
+    return gates
+
+
+def modulate(t_lr, w2, b2, img, out):
+    B, h, w, _ = t_lr.shape
+    _, Hh, Wh, _ = img.shape
+    hip.call("ffsr_modulate_f32", _ptr(t_lr), ld(t_lr), _ptr(w2), _ptr(b2), _ptr(img), ld(img), _ptr(out), ld(out), B,
+             h, w, Hh, Wh, _stream())
+
+
+def fusion_route(enh, hier, routing, fw, gates, diff, out):
+    B, Hh, Wh, _ = enh.shape
+    _, h, w, _ = routing.shape
+    hip.call("ffsr_fusion_route_f32", _ptr(enh), ld(enh), _ptr(hier), ld(hier), _ptr(routing), ld(routing), _ptr(fw),
+             _ptr(gates), ld(gates), _ptr(diff), ld(diff), _ptr(out), ld(out), B, h, w, Hh, Wh, _stream())
+
+
+def edge_final(sr, edge, gate, strength, lr, rscale, out):
+    B, Hh, Wh, _ = sr.shape
+    _, h, w, _ = lr.shape
+    hip.call("ffsr_edge_final_f32", _ptr(sr), ld(sr), _ptr(edge), ld(edge), _ptr(gate), ld(gate), _ptr(strength),
+             _ptr(lr), ld(lr), _ptr(rscale), _ptr(out), ld(out), B, h, w, Hh, Wh, _stream())
+
+
+# ---------------------------------------------------------------------------------------------- image boundary
+def u8_to_map(img_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 [B,H,W,3] (device) -> float map [B,H,W,3] / 255 with ld 4 (pad channel 0)."""
+    B, H, W, C = img_u8.shape
+    assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and img_u8.is_cuda
+    out = new_map(B, H, W, C, img_u8.device)
+    hip.call("ffsr_u8_to_f32", _ptr(img_u8), _ptr(out), ld(out), B * H * W, C, _stream())
+    return out
+
+
+def map_to_u8(x: torch.Tensor) -> torch.Tensor:
+    B, H, W, C = x.shape
+    out = torch.empty(B, H, W, C, dtype=torch.uint8, device=x.device)
+    hip.call("ffsr_f32_to_u8", _ptr(x), ld(x), _ptr(out), B * H * W, C, _stream())
+    return out
+
+
+def pad_reflect(x, Hp, Wp):
+    B, H, W, C = x.shape
+    if (Hp, Wp) == (H, W):
+        return x
+    out = new_map(B, Hp, Wp, C, x.device)
+    hip.call("ffsr_pad_reflect_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, H, W, Hp, Wp, C, _stream())
+    return out
+
+
+def crop(x, Ho, Wo, clamp=False, out=None):
+    B, H, W, C = x.shape
+    if out is None:
+        if (Ho, Wo) == (H, W) and not clamp:
+            return x
+        out = new_map(B, Ho, Wo, C, x.device)
+    hip.call("ffsr_crop_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, H, W, Ho, Wo, C, int(clamp), _stream())
+    return out

@@ -1,0 +1,394 @@
+"""Reference-compatible weights: seeded random initialisation and the checkpoint conventions of
+models/team29_FreqFusionSR/io.py:126-216 and src/models/expert_loader.py:73-118.
+
+The real checkpoints are a Google-Drive download that is not available offline (model_zoo/team29_FreqFusionSR/
+team29_FreqFusionSR.txt:7-8), so benchmarks and tests run on random weights of the exact architecture.  The
+generators below produce state_dicts with the reference's keys and shapes (checked against
+tests/golden/manifest.json, which was dumped from the reference modules), with every branch made live
+(non-zero NAFNet beta/gamma, biases, BN statistics) as SURVEY.md section 8d prescribes.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict
+
+import torch
+
+SD = Dict[str, torch.Tensor]
+
+EXPERT_FILES = {"drct": "DRCT-L_X4.pth", "grl": "GRL-B_SR_x4.pth", "nafnet": "NAFNet-SIDD-width64.pth",
+                "mamba": "MambaIR_x4.pth", "fusion": "fusion_best.pth"}
+
+
+class _Init:
+    def __init__(self, seed: int):
+        self.g = torch.Generator().manual_seed(seed)
+        self.sd: SD = {}
+
+    def normal(self, key, shape, std=0.02, mean=0.0):
+        self.sd[key] = torch.randn(shape, generator=self.g) * std + mean
+
+    def conv(self, key, cout, cin, k=1, bias=True, groups=1, kh=None, kw=None):
+        kh, kw = kh or k, kw or k
+        fan_in = cin // groups * kh * kw
+        self.normal(key + ".weight", (cout, cin // groups, kh, kw), std=0.7 / math.sqrt(fan_in))
+        if bias:
+            self.normal(key + ".bias", (cout,), std=0.02)
+
+    def linear(self, key, cout, cin, bias=True, std=None):
+        self.normal(key + ".weight", (cout, cin), std=std or 0.7 / math.sqrt(cin))
+        if bias:
+            self.normal(key + ".bias", (cout,), std=0.02)
+
+    def norm(self, key, c):
+        self.normal(key + ".weight", (c,), std=0.1, mean=1.0)
+        self.normal(key + ".bias", (c,), std=0.05)
+
+    def bn(self, key, c):
+        self.norm(key, c)
+        self.normal(key + ".running_mean", (c,), std=0.1)
+        self.sd[key + ".running_var"] = torch.rand((c,), generator=self.g) + 0.5
+
+    def const(self, key, value, shape=()):
+        self.sd[key] = torch.full(shape, float(value))
+
+
+def _sr_tail(I: _Init, embed, up="upsample."):
+    I.conv("conv_after_body", embed, embed, 3)
+    I.conv("conv_before_upsample.0", 64, embed, 3)
+    I.conv(up + "0", 256, 64, 3)
+    I.conv(up + "2", 256, 64, 3)
+    I.conv("conv_last", 3, 64, 3)
+
+
+def _cab(I: _Init, p, c, squeeze_c, mid_c):
+    I.conv(p + "cab.0", mid_c, c, 3)
+    I.conv(p + "cab.2", c, mid_c, 3)
+    I.conv(p + "cab.3.attention.1", squeeze_c, c, 1)
+    I.conv(p + "cab.3.attention.3", c, squeeze_c, 1)
+
+
+# ---------------------------------------------------------------------------------------------- DRCT-L
+def drct_state_dict(seed=1, embed=180, groups=12, heads=6, ws=16, gc=32, mlp_ratios=(2, 2, 2, 1, 1)) -> SD:
+    I = _Init(seed)
+    I.conv("conv_first", embed, 3, 3)
+    I.norm("patch_embed.norm", embed)
+    for i in range(groups):
+        for j in range(5):
+            dim = embed + gc * j
+            h = heads if j == 0 else heads - (dim % heads)
+            p = f"layers.{i}.swin{j + 1}."
+            I.norm(p + "norm1", dim)
+            I.normal(p + "attn.relative_position_bias_table", ((2 * ws - 1) ** 2, h), std=0.3)
+            I.linear(p + "attn.qkv", 3 * dim, dim)
+            I.linear(p + "attn.proj", dim, dim)
+            I.norm(p + "norm2", dim)
+            hid = int(dim * mlp_ratios[j])
+            I.linear(p + "mlp.fc1", hid, dim)
+            I.linear(p + "mlp.fc2", dim, hid)
+            I.conv(f"layers.{i}.adjust{j + 1}", gc if j < 4 else embed, dim, 1)
+    I.norm("norm", embed)
+    _sr_tail(I, embed)
+    return I.sd
+
+
+# ---------------------------------------------------------------------------------------------- GRL-B
+def grl_state_dict(seed=2, embed=180, depths=(4, 4, 8, 8, 8, 4, 4), heads=3) -> SD:
+    I = _Init(seed)
+    I.conv("conv_first", embed, 3, 3)
+    I.norm("norm_start", embed)
+    for i, depth in enumerate(depths):
+        for j in range(depth):
+            p = f"layers.{i}.blocks.{j}."
+            I.linear(p + "attn.qkv.body", 3 * embed, embed)
+            I.linear(p + "attn.anchor.body.0.reduction", embed // 2, embed)
+            for t in ("window_attn.attn_transform", "stripe_attn.attn_transform1", "stripe_attn.attn_transform2"):
+                I.normal(p + f"attn.{t}.logit_scale", (heads, 1, 1), std=0.2, mean=math.log(10.0))
+                I.linear(p + f"attn.{t}.cpb_mlp.0", 512, 2, std=0.5)
+                I.linear(p + f"attn.{t}.cpb_mlp.2", heads, 512, bias=False, std=0.05)
+            I.linear(p + "attn.proj", embed, embed)
+            I.norm(p + "norm1", embed)
+            _cab(I, p + "conv.", embed, embed // 18, embed // 4)
+            I.linear(p + "mlp.fc1", 2 * embed, embed)
+            I.linear(p + "mlp.fc2", embed, 2 * embed)
+            I.norm(p + "norm2", embed)
+        I.conv(f"layers.{i}.conv", embed, embed, 3)
+    I.norm("norm_end", embed)
+    _sr_tail(I, embed, up="upsample.up.")
+    return I.sd
+
+
+# ---------------------------------------------------------------------------------------------- NAFNet
+def nafnet_state_dict(seed=3, width=64, enc=(2, 2, 4, 8), mid=12, dec=(2, 2, 2, 2)) -> SD:
+    I = _Init(seed)
+
+    def block(p, c):
+        I.conv(p + "conv1", 2 * c, c, 1)
+        I.conv(p + "conv2", 2 * c, 2 * c, 3, groups=2 * c)
+        I.conv(p + "conv3", c, c, 1)
+        I.conv(p + "sca.1", c, c, 1)
+        I.conv(p + "conv4", 2 * c, c, 1)
+        I.conv(p + "conv5", c, c, 1)
+        I.norm(p + "norm1", c)
+        I.norm(p + "norm2", c)
+        I.normal(p + "beta", (1, c, 1, 1), std=0.3)
+        I.normal(p + "gamma", (1, c, 1, 1), std=0.3)
+
+    I.conv("intro", width, 3, 3)
+    I.conv("ending", 3, width, 3)
+    c = width
+    for i, n in enumerate(enc):
+        for j in range(n):
+            block(f"encoders.{i}.{j}.", c)
+        I.conv(f"downs.{i}", 2 * c, c, 2)
+        c *= 2
+    for j in range(mid):
+        block(f"middle_blks.{j}.", c)
+    for i, n in enumerate(dec):
+        I.conv(f"ups.{i}.0", 2 * c, c, 1, bias=False)
+        c //= 2
+        for j in range(n):
+            block(f"decoders.{i}.{j}.", c)
+    return I.sd
+
+
+# ---------------------------------------------------------------------------------------------- MambaIR
+def mambair_state_dict(seed=4, embed=180, depths=(6, 6, 6, 6, 6, 6), d_state=16) -> SD:
+    I = _Init(seed)
+    d_inner, R = 2 * embed, math.ceil(embed / 16)
+    I.conv("conv_first", embed, 3, 3)
+    I.norm("patch_embed.norm", embed)
+    for i, depth in enumerate(depths):
+        for j in range(depth):
+            p = f"layers.{i}.residual_group.blocks.{j}."
+            I.normal(p + "skip_scale", (embed,), std=0.1, mean=1.0)
+            I.normal(p + "skip_scale2", (embed,), std=0.1, mean=1.0)
+            I.norm(p + "ln_1", embed)
+            s = p + "self_attention."
+            I.normal(s + "x_proj_weight", (4, R + 2 * d_state, d_inner), std=0.7 / math.sqrt(d_inner))
+            I.normal(s + "dt_projs_weight", (4, d_inner, R), std=R ** -0.5 * 0.5)
+            dt = torch.exp(torch.rand((4, d_inner), generator=I.g) * (math.log(0.1) - math.log(0.001)) + math.log(0.001))
+            I.sd[s + "dt_projs_bias"] = dt + torch.log(-torch.expm1(-dt))
+            A = torch.arange(1, d_state + 1, dtype=torch.float32).repeat(4 * d_inner, 1)
+            I.sd[s + "A_logs"] = torch.log(A) + 0.1 * torch.randn(A.shape, generator=I.g)
+            I.normal(s + "Ds", (4 * d_inner,), std=0.1, mean=1.0)
+            I.linear(s + "in_proj", 2 * d_inner, embed, bias=False)
+            I.conv(s + "conv2d", d_inner, d_inner, 3, groups=d_inner)
+            I.norm(s + "out_norm", d_inner)
+            I.linear(s + "out_proj", embed, d_inner, bias=False)
+            _cab(I, p + "conv_blk.", embed, embed // 30, embed // 3)
+            I.norm(p + "ln_2", embed)
+        I.conv(f"layers.{i}.conv", embed, embed, 3)
+    I.norm("norm", embed)
+    _sr_tail(I, embed)
+    return I.sd
+
+
+# ---------------------------------------------------------------------------------------------- fusion
+DB4_LO = [-0.010597401784997278, 0.032883011666982945, 0.030841381835986965, -0.18703481171888114,
+          -0.027983769416983849, 0.63088076792959036, 0.71484657055291582, 0.23037781330885523]
+DB4_HI = [-0.23037781330885523, 0.71484657055291582, -0.63088076792959036, -0.027983769416983849,
+          0.18703481171888114, 0.030841381835986965, -0.032883011666982945, -0.010597401784997278]
+
+
+def dct_basis(n=8) -> torch.Tensor:
+    k = torch.arange(n, dtype=torch.float64)[:, None]
+    m = torch.arange(n, dtype=torch.float64)[None, :]
+    D = math.sqrt(2.0 / n) * torch.cos(math.pi * k * (2 * m + 1) / (2 * n))
+    D[0] = math.sqrt(1.0 / n)
+    return D.float()
+
+
+def zigzag_masks(n=8):
+    order = torch.zeros(n, n, dtype=torch.long)
+    idx = 0
+    for s in range(2 * n - 1):
+        rng = range(min(s, n - 1), max(0, s - n + 1) - 1, -1) if s % 2 == 0 else range(max(0, s - n + 1), min(s, n - 1) + 1)
+        for i in rng:
+            order[i, s - i] = idx
+            idx += 1
+    lo, hi = n * n // 3, 2 * n * n // 3
+    return (order < lo).float(), ((order >= lo) & (order < hi)).float(), (order >= hi).float()
+
+
+def fusion_state_dict(seed=5) -> SD:
+    I = _Init(seed)
+    I.const("residual_scale", 0.1)
+    p = "freq_decomp."
+    I.normal(p + "dct.band_scale", (3,), std=0.1, mean=1.0)
+    I.sd[p + "dct.dct_basis"] = dct_basis()
+    I.sd[p + "dct.dct_basis_t"] = dct_basis().t().contiguous()
+    for k, m in zip(("low_mask", "mid_mask", "high_mask"), zigzag_masks()):
+        I.sd[p + "dct." + k] = m
+    I.normal(p + "dwt.subband_scale", (4,), std=0.1, mean=1.0)
+    lo, hi = torch.tensor(DB4_LO), torch.tensor(DB4_HI)
+    I.sd[p + "dwt.lo_row"] = lo.reshape(1, 1, 1, 8).repeat(3, 1, 1, 1)
+    I.sd[p + "dwt.hi_row"] = hi.reshape(1, 1, 1, 8).repeat(3, 1, 1, 1)
+    I.sd[p + "dwt.lo_col"] = lo.reshape(1, 1, 8, 1).repeat(3, 1, 1, 1)
+    I.sd[p + "dwt.hi_col"] = hi.reshape(1, 1, 8, 1).repeat(3, 1, 1, 1)
+    ax = torch.linspace(-1, 1, 64)
+    yy, xx = torch.meshgrid(ax, ax, indexing="ij")
+    I.sd[p + "fft.freq_mask_logits"] = (3.0 * (0.5 - torch.sqrt(xx ** 2 + yy ** 2)))[None, None] \
+        + 0.2 * torch.randn((1, 1, 64, 64), generator=I.g)
+    I.const(p + "fft.temperature", 5.0)
+    I.normal(p + "fft.band_scale", (2,), std=0.1, mean=1.0)
+
+    def lka_block(q, c):
+        I.const(q + "scale1", 0.1)
+        I.const(q + "scale2", 0.1)
+        I.bn(q + "norm1", c)
+        I.conv(q + "lka.local_conv", c, c, 5, bias=False, groups=c)
+        I.conv(q + "lka.h_conv", c, c, groups=c, bias=False, kh=1, kw=21)
+        I.conv(q + "lka.v_conv", c, c, groups=c, bias=False, kh=21, kw=1)
+        I.conv(q + "lka.pw_conv", c, c, 1, bias=False)
+        I.bn(q + "lka.bn", c)
+        I.bn(q + "norm2", c)
+        I.conv(q + "ffn.0", 2 * c, c, 1)
+        I.conv(q + "ffn.2", c, 2 * c, 1)
+
+    def mha(q, e):
+        I.normal(q + "in_proj_weight", (3 * e, e), std=0.7 / math.sqrt(e))
+        I.normal(q + "in_proj_bias", (3 * e,), std=0.02)
+        I.linear(q + "out_proj", e, e)
+
+    p = "cross_band."
+    I.conv(p + "band_proj", 64, 3, 1)
+    mha(p + "band_attention.", 64)
+    I.norm(p + "norm", 64)
+    lka_block(p + "lka_block.", 64)
+    I.conv(p + "out_proj", 3, 64, 1)
+    p = "collaborative."
+    for n, c in (("drct", 180), ("grl", 180), ("nafnet", 64), ("mamba", 180)):
+        I.conv(p + f"align_layers.{n}", 128, c, 1)
+    mha(p + "cross_attn.", 128)
+    I.norm(p + "norm1", 128)
+    I.norm(p + "norm2", 128)
+    I.linear(p + "ffn.0", 256, 128)
+    I.linear(p + "ffn.2", 128, 256)
+    lka_block(p + "lka_global.", 128)
+    for i in range(4):
+        I.conv(p + f"modulation.{i}.0", 32, 128, 1)
+        I.conv(p + f"modulation.{i}.2", 3, 32, 1)
+    p = "multi_res."
+    I.const(p + "residual_weight_1_2", 0.2)
+    I.const(p + "residual_weight_2_3", 0.2)
+    for s, (cin, c1, c2) in enumerate(((12, 64, 64), (76, 64, 64), (76, 64, 32)), start=1):
+        I.conv(p + f"stage{s}_conv.0", c1, cin, 3)
+        I.conv(p + f"stage{s}_conv.2", c2, c1, 3)
+        I.conv(p + f"stage{s}_gate.gate.0", c2 // 4, c2, 1)
+        I.conv(p + f"stage{s}_gate.gate.2", 1, c2 // 4, 1)
+        I.const(p + f"stage{s}_res.scale", 0.1)
+        I.conv(p + f"stage{s}_res.block.0", c2, c2, 3, bias=False)
+        I.conv(p + f"stage{s}_res.block.2", c2, c2, 3, bias=False)
+    I.conv(p + "to_rgb.0", 16, 32, 3)
+    I.conv(p + "to_rgb.2", 3, 16, 3)
+    I.conv("freq_weight_conv.0", 16, 3, 1)
+    I.conv("freq_weight_conv.2", 4, 16, 1)
+    p = "dynamic_selector."
+    I.const(p + "temperature", 10.0)
+    I.conv(p + "difficulty_net.0", 32, 3, 3)
+    I.conv(p + "difficulty_net.2", 32, 32, 3)
+    I.conv(p + "difficulty_net.4", 1, 32, 3)
+    I.conv(p + "gate_net.0", 32, 3, 3)
+    I.conv(p + "gate_net.2", 32, 32, 3)
+    I.conv(p + "gate_net.4", 4, 32, 1)
+    I.conv("refine.0", 128, 3, 3)
+    for i in (2, 4, 6, 8):
+        I.conv(f"refine.{i}", 128, 128, 3)
+    I.conv("refine.10", 3, 128, 3)
+    p = "edge_enhance."
+    I.sd[p + "level_weights"] = torch.ones(3) / 3 + 0.1 * torch.randn((3,), generator=I.g)
+    I.const(p + "edge_strength", 0.15)
+    c = torch.arange(5, dtype=torch.float32) - 2
+    g = torch.exp(-(c ** 2) / (2 * 1.5 ** 2))
+    g = g / g.sum()
+    I.sd[p + "gaussian.kernel"] = (g[:, None] * g[None, :]).expand(3, 1, 5, 5).contiguous()
+    for i in range(3):
+        q = p + f"edge_refiners.{i}."
+        I.conv(q + "conv1", 32, 3, 3)
+        I.conv(q + "conv2", 32, 32, 3)
+        I.conv(q + "conv3", 32, 32, 3)
+        I.conv(q + "proj", 32, 3, 1)
+        I.conv(q + "attn.attn.0", 8, 32, 1)
+        I.conv(q + "attn.attn.2", 1, 8, 3)
+    I.conv(p + "fusion.0", 32, 96, 3)
+    I.conv(p + "fusion.2", 3, 32, 3)
+    I.conv(p + "edge_gate.0", 16, 6, 3)
+    I.conv(p + "edge_gate.2", 1, 16, 3)
+    return I.sd
+
+
+def random_weights(seed=0, small=False) -> Dict[str, SD]:
+    """All five state_dicts.  small=True: reduced-depth experts for smoke tests (same block types)."""
+    if small:
+        return {"drct": drct_state_dict(seed + 1, groups=1), "grl": grl_state_dict(seed + 2, depths=(2,)),
+                "nafnet": nafnet_state_dict(seed + 3, width=16, enc=(1, 1, 1, 1), mid=1, dec=(1, 1, 1, 1)),
+                "mamba": mambair_state_dict(seed + 4, depths=(1,)), "fusion": fusion_state_dict(seed + 5)}
+    return {"drct": drct_state_dict(seed + 1), "grl": grl_state_dict(seed + 2), "nafnet": nafnet_state_dict(seed + 3),
+            "mamba": mambair_state_dict(seed + 4), "fusion": fusion_state_dict(seed + 5)}
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints
+def _unwrap(ckpt, keys):
+    if isinstance(ckpt, dict):
+        for k in keys:
+            if k in ckpt and isinstance(ckpt[k], dict):
+                return ckpt[k]
+    return ckpt
+
+
+def _strip(sd, prefixes):
+    out = {}
+    for k, v in sd.items():
+        for p in prefixes:
+            if k.startswith(p):
+                k = k[len(p):]
+        out[k] = v
+    return out
+
+
+def load_checkpoint(path: str, kind: str) -> SD:
+    """Reads one of the five checkpoint files with the reference's wrapper/prefix conventions
+    (expert_loader.py:83-95, :378; io.py:165-167, :197-205).  Unlike the reference this uses
+    ``weights_only=True`` (nothing from the file is executed)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    if kind in ("drct", "grl"):
+        sd = _strip(_unwrap(ckpt, ("params_ema", "params", "state_dict", "model")), ("module.",))
+    elif kind == "nafnet":
+        sd = _unwrap(ckpt, ("params",))
+    elif kind == "mamba":
+        sd = _strip(_unwrap(ckpt, ("params", "state_dict", "model")), ("module.",))
+    elif kind == "fusion":
+        sd = _strip(_unwrap(ckpt, ("model_state_dict", "state_dict")), ("module.", "model."))
+    else:
+        raise ValueError(kind)
+    return {k: v for k, v in sd.items() if isinstance(v, torch.Tensor)}
+
+
+def merge_into(template: SD, loaded: SD) -> SD:
+    """Copy only same-shape keys and never raise on missing ones (expert_loader.py:97-111, io.py:207-212)."""
+    out = dict(template)
+    for k, v in loaded.items():
+        if k in out and tuple(out[k].shape) == tuple(v.shape):
+            out[k] = v.float()
+    return out
+
+
+def load_model_dir(model_dir: str, templates: Dict[str, SD] = None) -> Dict[str, SD]:
+    """model_dir holds the five files of io.py:130-135; keys absent / mis-shaped keep their template value."""
+    templates = templates or random_weights()
+    out = {}
+    for kind, fname in EXPERT_FILES.items():
+        path = os.path.join(model_dir, fname)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        out[kind] = merge_into(templates[kind], load_checkpoint(path, kind))
+    return out
+
+
+def save_model_dir(model_dir: str, weights: Dict[str, SD]):
+    os.makedirs(model_dir, exist_ok=True)
+    wrap = {"drct": "params_ema", "grl": "params", "nafnet": "params", "mamba": "params", "fusion": "model_state_dict"}
+    for kind, fname in EXPERT_FILES.items():
+        torch.save({wrap[kind]: weights[kind]}, os.path.join(model_dir, fname))

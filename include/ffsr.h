@@ -1,0 +1,168 @@
+/*
+ * libffsr_hip.so -- C ABI of the MI355X (gfx950) kernels behind the FreqFusionSR x4 inference hot path.
+ *
+ * The reference (Nikhil-AI-Labs/Image-Super-Resolution) is 100 % Python and dispatches every operator to ATen;
+ * its only native seam is mamba_ssm's selective_scan_fn (mambair_arch.py:276, :356-362).  The "FFI" a maintainer
+ * binds is therefore ctypes: each entry point below replaces the ATen / mamba_ssm call
+ * sequence of one reference function, cited as file:line relative to /root/reference.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 data owned by the caller; nothing is allocated or freed inside;
+ *    `stream` is a hipStream_t (NULL = default stream); calls are asynchronous and thread-safe per stream.
+ *  - activations are channels-last: a tensor [B, H, W, C] is a matrix of B*H*W pixel rows with a row stride
+ *    `ld*` in floats (ld >= C, ld % 4 == 0 for the vectorised paths; padded channels must hold finite values,
+ *    zero where a consumer contracts over them).
+ *  - return value: 0 = launched, FFSR_EINVAL (-1) = rejected argument, FFSR_ELAUNCH (-2) = HIP launch error.
+ *  - activation codes: 0 none, 1 GELU(erf), 2 ReLU, 3 LeakyReLU(slope), 4 sigmoid, 5 SiLU.
+ */
+#ifndef FFSR_H
+#define FFSR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFSR_OK 0
+#define FFSR_EINVAL (-1)
+#define FFSR_ELAUNCH (-2)
+
+/* Implicit-GEMM convolution / linear layer on the f32 MFMA.
+ *   out[pix, n] = res[pix, n] * rvec[n] * rscale + act(sum_k A[pix, k] * wgt[n, k] + bias[n]) * cvec[n] * cscale
+ * in: [B,H,W,ldi] (Cin channels used, Cin % 4 == 0); wgt: [N, KH*KW*Cin] (tap-major, channel-minor);
+ * bias/res/cvec/rvec/akscale may be NULL.  akscale [B, Cin] (1x1 only) scales the A operand per (batch, k)
+ * with akrows pixels per batch.  shuffle = 2 fuses nn.PixelShuffle(2) into the store (out/res are then
+ * [B, 2Ho, 2Wo, ld] with N/4 channels).  tile_hint 0 = automatic.
+ * Replaces: nn.Linear / nn.Conv2d everywhere on the path, e.g. drct_arch.py:166,168,83-85 (qkv, proj, Mlp),
+ * :601-620 (Upsample conv + PixelShuffle), nafnet_arch.py:110-131 (conv1/3/4/5, SCA scale via akscale) and
+ * :181-187 (ups), mambair_arch.py:238,279 (in/out_proj), :346 (x_proj, all 4 directions in one GEMM),
+ * enhanced_fusion_v2.py:569-576 (refine stack), hierarchical_fusion.py:90-124, edge_enhancement.py:102-177. */
+int ffsr_conv2d_f32(const float* in, const float* wgt, const float* bias, float* out, const float* res,
+                    const float* cvec, const float* rvec, const float* akscale, int B, int H, int W, int Cin, int ldi,
+                    int N, int ldo, int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                    float cscale, float rscale, int shuffle, int akrows, int tile_hint, void* stream);
+
+/* out = LayerNorm_C(x) * gamma + beta (+ res1) (+ res2); biased variance, rows of C <= 1024.
+ * Replaces nn.LayerNorm (drct_arch.py:385, grl mixed_attn_block_efficient.py:543-554 incl. the post-norm residual
+ * sums, mambair_arch.py:417-419) and NAFNet's LayerNorm2d (nafnet_arch.py:26-44). */
+int ffsr_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out, int ldo,
+                       const float* res1, int ldr1, const float* res2, int ldr2, int M, int C, void* stream);
+
+/* out = clamp(act(x * pre) * alpha * cscale[n] + beta + cbias[n], lo, hi) (cscale, cbias [C] optional; clamp only if
+ * do_clamp).  Covers eval-mode BatchNorm (large_kernel_attention.py:143), mean shifts, clamps, activations. */
+int ffsr_unary_f32(const float* x, int ldx, float* out, int ldo, long long M, int C, int act, float slope, float pre,
+                   float alpha, float beta, const float* cscale, const float* cbias, int do_clamp, float lo, float hi,
+                   void* stream);
+
+/* out = alpha * a * avec[n] + beta * b * bvec[m / rows_per_batch, n]  (avec [C], b, bvec [B, C] optional).
+ * Replaces the residual / skip-scale / channel-attention combinations, e.g. mambair_arch.py:418-419,
+ * ChannelAttention (mambair_arch.py:20-38, grl mixed_attn_block.py:942-961). */
+int ffsr_scale_add_f32(const float* a, int lda, const float* avec, const float* b, int ldb, const float* bvec,
+                       int rows_per_batch, float* out, int ldo, long long M, int C, float alpha, float beta, void* stream);
+
+/* out = alpha * a * b' + gamma * c;  b' = b[m, n] (bmode 0) or b[m * ldb] broadcast over channels (bmode 1).
+ * Replaces SimpleGate (nafnet_arch.py:47-55), LKA / spatial gates (large_kernel_attention.py:105,
+ * hierarchical_fusion.py:42, edge_enhancement.py:88). */
+int ffsr_mul_add_f32(const float* a, int lda, const float* b, int ldb, int bmode, const float* c, int ldc, float* out,
+                     int ldo, long long M, int C, float alpha, float gamma, void* stream);
+
+/* out[b, c] = mean over the R rows of batch b (nn.AdaptiveAvgPool2d(1)); part: scratch [B, nchunk, C]. */
+int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part, int B, int R, int C, int nchunk, void* stream);
+
+/* Depthwise KHxKW convolution, stride 1, zero padding; w tap-major [KH*KW, C]; act fused.
+ * Replaces mambair_arch.py:239-247,378 (dw3x3 + SiLU) and the LKA chain large_kernel_attention.py:92-99. */
+int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo, int B, int H,
+                      int W, int C, int KH, int KW, int pad_h, int pad_w, int act, void* stream);
+
+/* NAFBlock middle: t = dw3x3(in [..,2C]); out[.., c] = t[c] * t[c + C]; pooled[b, c] = spatial mean of out.
+ * Replaces nafnet_arch.py:115-117 (conv2, SimpleGate, AdaptiveAvgPool2d).  part: scratch [B, nchunk, C]. */
+int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                             float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False, size=(Ho, Wo)); out = (accumulate ? out : 0) + mul * value. */
+int ffsr_bilinear_f32(const float* in, int ldi, float* out, int ldo, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                      float mul, int accumulate, void* stream);
+/* F.interpolate(scale_factor=scale, mode='bicubic', align_corners=False) (A = -0.75): nafnet/__init__.py:128-133. */
+int ffsr_bicubic_up_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int scale,
+                        void* stream);
+/* F.avg_pool2d(x, 2, 2): grl mixed_attn_block.py:714-737 (anchors), edge_enhancement.py:196. */
+int ffsr_avgpool2_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, void* stream);
+
+/* Host-boundary pixel helpers of models/team29_FreqFusionSR/io.py: _uint2tensor4 :100 (uint8 HWC -> float / 255),
+ * _tensor2uint :107 (clamp, * 255, round-half-even, uint8), _pad16 :71 (reflect, right/bottom), _unpad :81 and the
+ * feature crops :234,245,268 (optionally with the experts' clamp(0,1), expert_loader.py:441,457). */
+int ffsr_u8_to_f32(const unsigned char* in, float* out, int ldo, long long M, int C, void* stream);
+int ffsr_f32_to_u8(const float* in, int ldi, unsigned char* out, long long M, int C, void* stream);
+int ffsr_pad_reflect_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Hp, int Wp, int C,
+                         void* stream);
+int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Ho, int Wo, int C,
+                  int do_clamp, void* stream);
+
+/* DRCT (shifted) window attention, fused: softmax(q k^T * scale + bias (+ shift mask)) v.
+ * qkv [B*H*W, ldq]: q | k | v, each [heads][C/heads]; bias dense [heads, ws*ws, ws*ws]; roll / window
+ * partition / reverse / mask folded into addressing.  Replaces drct_arch.py:175-206 and :376-414. */
+int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* out, int ldo, int B, int H, int W, int C,
+                         int heads, int ws, int shift, float scale, void* stream);
+
+/* GRL 8x8 cosine window attention (mixed_attn_block_efficient.py:77-94,128-165) on the columns
+ * [col0, col0 + 3*heads*hd) of qkv; biasT [heads, 64 keys, 64 queries] = 16*sigmoid(CPB-MLP) transposed;
+ * logit [heads] = exp(min(logit_scale, ln 100)).  Output written at columns ocol0 + head*hd. */
+int ffsr_grl_window_attn_f32(const float* qkv, int ldq, int col0, const float* biasT, const float* logit, float* out,
+                             int ldo, int ocol0, int B, int H, int W, int heads, int hd, int shift, void* stream);
+/* GRL anchored stripe attention, both hops fused (mixed_attn_block_efficient.py:215-270); anchor [B,H/2,W/2,lda]. */
+int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, const float* anchor, int lda, const float* bias1T,
+                             const float* bias2T, const float* logit1, const float* logit2, float* out, int ldo,
+                             int ocol0, int B, int H, int W, int heads, int hd, void* stream);
+
+/* nn.MultiheadAttention core (eval) on S sequences of T tokens (T = 9 bands or 4 experts), heads of 16:
+ * qkv [S*T, 3E] -> out [S*T, E].  Replaces large_kernel_attention.py:222-233, 385-396 (between in/out proj). */
+int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo, long long S, int T, int E, int heads,
+                       void* stream);
+
+/* Four-direction selective scan with the dt projection fused (mamba_ssm selective_scan_fn as called at
+ * mambair_arch.py:339-369 incl. the direction gather :343-344 and inverse scatter :365-369).
+ * u [B, L, ldu]; xdbl [B, L, ldx] = per direction k: dt(R) | B(16) | C(16) at column k*(R+32);
+ * dtw [4, Dm, R]; dtb, Dv [4, Dm]; A [4, Dm, 16] (= -exp(A_logs)); y [4][B, L, ldy] per-direction outputs in
+ * pixel order; hstate/decay: scratch [B, 4, ceil(L/chunk), Dm, 16] each. */
+int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw, const float* dtb,
+                             const float* A, const float* Dv, float* y, int ldy, float* hstate, float* decay, int B,
+                             int H, int W, int Dm, int R, int d_state, int chunk, void* stream);
+/* out = LayerNorm(y0 + y1 + y2 + y3) * silu(z): mambair_arch.py:380-384.  ystride = elements between directions. */
+int ffsr_mamba_norm_gate_f32(const float* y, long long ystride, int ldy, const float* z, int ldz, const float* gamma,
+                             const float* beta, float eps, float* out, int ldo, int M, int C, void* stream);
+
+/* Phase-2 band split into bands[pixel][9][4] (ldb = 36): multi_domain_frequency.py:146-196 (DCT), :251-299 (DWT,
+ * sub [B, Hd, Wd, 16] then upsampled with ffsr_bilinear_f32), :352-385 (FFT, as separable dense DFTs;
+ * twW/twH = (cos, sin)(2 pi j / n) tables, mask [H, W/2+1], work = 10 * B*3*H*(W/2+1) floats). */
+int ffsr_dct_bands_f32(const float* img, int ldi, const float* D, const float* masks, const float* scale, float* bands,
+                       int ldb, int B, int H, int W, void* stream);
+int ffsr_dwt_db4_f32(const float* img, int ldi, const float* lo, const float* hi, float* sub, int B, int H, int W,
+                     void* stream);
+int ffsr_fft_bands_f32(const float* img, int ldi, const float* twW, const float* twH, const float* mask,
+                       const float* scale, float* work, float* bands, int ldb, int B, int H, int W, void* stream);
+
+/* gates = sigmoid(T * (raw - (0.7 - 0.5 * diff))) / clamp(sum_e gates + 1e-8, min 0.3): DynamicExpertSelector.forward,
+ * enhanced_fusion_v2.py:462-465.  raw [M, 4], diff [M, 1], temperature = device scalar. */
+int ffsr_selector_gates_f32(const float* raw, int ldr, const float* diff, int ldd, const float* temperature,
+                            float* gates, int ldg, long long M, void* stream);
+/* Phase-4 tail (large_kernel_attention.py:410-427): t_lr [B,h,w,ldt] = modulation[i].0 (1x1 128->32) applied at LR
+ * (hoisted in front of the bilinear upsample -- both linear); per HR pixel: mod = sigmoid(W2 gelu(bilinear(t_lr)) + b2),
+ * out[.., 0..2] = clamp(img * (1 + 0.2 * (mod - 0.5)), 0, 1).  w2 [3, 32], b2 [3]. */
+int ffsr_modulate_f32(const float* t_lr, int ldt, const float* w2, const float* b2, const float* img, int ldi,
+                      float* out, int ldo, int B, int h, int w, int Hh, int Wh, void* stream);
+/* Phases 5b + 5c + 6 fused at HR (enhanced_fusion_v2.py:735-774): enh [.., 12] = 4 enhanced expert images,
+ * hier [.., 3] = sigmoid output of the hierarchical fusion, routing [B,h,w,ldr] = routing_lr,
+ * fw = freq_weight_conv packed [W1 16x3 | b1 16 | W2 4x16 | b2 4], gates [B,h,w,4], diff [B,h,w,1] at LR.
+ * out [.., 4] = (1 - bw) * (0.7 hier + 0.3 freq_fused) + bw * dynamic_fused, channel 3 zeroed. */
+int ffsr_fusion_route_f32(const float* enh, int lde, const float* hier, int ldh, const float* routing, int ldr,
+                          const float* fw, const float* gates, int ldg, const float* diff, int ldd, float* out, int ldo,
+                          int B, int h, int w, int Hh, int Wh, void* stream);
+/* out = clamp(clamp(sr + gate * strength * edge, 0, 1) + rscale * bilinear(lr), 0, 1): edge_enhancement.py:261-262 and
+ * enhanced_fusion_v2.py:788-795.  gate [.., 1] already sigmoid-ed; strength, rscale = device scalars. */
+int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, const float* gate, int ldg,
+                        const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo, int B,
+                        int h, int w, int Hh, int Wh, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFSR_H */
