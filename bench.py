@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Benchmark of the FreqFusionSR x4 hot path on MI355X (contract: see the task description / DESIGN.md).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one 340x510 LR image (BASELINE.json's metric size: 510x340 -> 2040x1360) through the full hot path --
+pad16 -> DRCT-L, GRL-B, NAFNet-w64, MambaIR -> 7-phase fusion -- with random-init weights of the exact architecture
+and a synthetic LR image already resident in HBM.  value = output megapixels / s of the whole job (all ranks);
+multi-GPU is image-parallel (weak scaling: every rank processes K images, weights broadcast once over RCCL, no
+collective in the forward pass).
+
+Also on the JSON line:
+  roofline     -- the dominant kernel conv_gemm_kernel (f32 MFMA implicit GEMM: every linear / conv of the path):
+                  algorithmic FLOPs per launch / mean launch duration, timed with events on the launch stream
+                  during one extra instrumented (untimed-for-`value`) step.
+  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path) on the box's host cores, rank 0 / N=1
+                  only, on a bounded sample (one 64x64 LR tile, full-size experts).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_LR, W_LR, SCALE = 340, 510, 4
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth_lr(seed, h, w):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(1, 3, h, w, generator=g)
+    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (2, 2, 2, 2), mode="reflect"), 5, 1)
+    x = (x - x.amin()) / (x.amax() - x.amin())
+    return torch.floor(x * 256).clamp(0, 255) / 255.0
+
+
+def cpu_baseline(weights, naf_cfg=None):
+    """Oracle (torch-CPU port of the reference path) on ONE 64x64 tile; returns the cpu_baseline object."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from ffsr_oracle import pipeline
+    from ffsr_oracle.scan_c import selective_scan_c          # same recurrence as scan.py, in C + OpenMP
+    lr = synth_lr(1234, 64, 64)
+    cores = min(16, os.cpu_count() or 1)                     # the box's CPU share for one GPU
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    weights = {m: {k: v.detach().float().cpu() for k, v in sd.items()} for m, sd in weights.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = pipeline.process_image(weights, lr, naf_cfg=naf_cfg, scan_fn=selective_scan_c)
+    dt = time.perf_counter() - t0
+    mp = out.shape[-1] * out.shape[-2] / 1e6
+    return {"value": mp / dt, "unit": "output MP/s", "cores": cores, "kind": "port",
+            "sample": f"1 x 64x64 LR tile -> 256x256 (0.0655 MP), 4 experts + fusion, {dt:.1f} s of CPU work, un-warmed"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=H_LR)
+    ap.add_argument("--width", type=int, default=W_LR)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
+    args = ap.parse_args()
+
+    W = importlib.import_module("image-super-resolution_amd.weights")
+    E = importlib.import_module("image-super-resolution_amd.engine")
+    S = importlib.import_module("image-super-resolution_amd.shard")
+    ops = importlib.import_module("image-super-resolution_amd.ops")
+
+    T0 = time.perf_counter()
+    rank, world = S.rank_world()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    S.init_process_group("nccl")
+
+    weights = W.random_weights(seed=0, small=args.small)
+    weights = S.broadcast_weights(weights, device)          # RCCL over xGMI, rank 0's values win (no-op at N=1)
+    eng = E.Engine(weights, device)
+    h, w = args.height, args.width
+    lrs = [E.nchw_to_map(synth_lr(1234 + rank * 1000 + i, h, w), device) for i in range(max(1, min(args.steps, 4)))]
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log(f"engine ready; warm-up x{args.warmup} on {h}x{w} LR")
+    for i in range(args.warmup):
+        eng.process(lrs[i % len(lrs)])
+        torch.cuda.synchronize(device)
+        log(f"warm-up step {i} done")
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.process(lrs[i % len(lrs)])
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    log(f"timed {args.steps} steps: {1e3 * dt / args.steps:.1f} ms/step")
+
+    mp_per_image = (h * SCALE) * (w * SCALE) / 1e6
+    value = world * args.steps * mp_per_image / dt
+
+    # ---- roofline of the dominant kernel: one extra instrumented step on the same stream
+    ops.CONV_PROFILE = []
+    eng.process(lrs[0])
+    torch.cuda.synchronize(device)
+    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    dur_ms = [a.elapsed_time(b) for a, b, _ in prof]
+    flops = sum(f for _, _, f in prof)
+    conv_s = sum(dur_ms) / 1e3
+    t1 = time.perf_counter()
+    eng.process(lrs[0])
+    torch.cuda.synchronize(device)
+    step_s = time.perf_counter() - t1
+    achieved = flops / conv_s / 1e12
+    # per-expert split of one step (diagnostic, stderr only)
+    if rank == 0:
+        lp = ops.pad_reflect(lrs[0], (h + 15) // 16 * 16, (w + 15) // 16 * 16)
+        for name, fn in (("drct", eng.drct), ("grl", eng.grl), ("nafnet", eng.nafnet), ("mamba", eng.mamba)):
+            torch.cuda.synchronize(device)
+            t2 = time.perf_counter()
+            fn(lp)
+            torch.cuda.synchronize(device)
+            log(f"  {name:7s} {1e3 * (time.perf_counter() - t2):8.1f} ms")
+        log(f"  conv/GEMM kernel: {len(prof)} launches, {flops / 1e12:.2f} TFLOP, {conv_s * 1e3:.1f} ms -> {achieved:.1f} TFLOP/s; "
+            f"whole step {step_s * 1e3:.1f} ms")
+    roofline = {"kernel": "conv_gemm_kernel (f32 MFMA implicit GEMM)", "bound": "mfma", "achieved": achieved,
+                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": len(prof), "flops_per_launch": flops / len(prof),
+                "mean_launch_us": 1e3 * sum(dur_ms) / len(prof), "kernel_share_of_step": conv_s / step_s}
+
+    if rank == 0:
+        line = {"metric": "SR output megapixels/s (x4, 510x340 LR -> 2040x1360, full 4-expert + 7-phase fusion)",
+                "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic (seeded LR images; random-init weights of the exact architecture)",
+                "config": {"workload": f"CompleteEnhancedFusionSR hot path: {w}x{h} LR image per step per GPU "
+                                       f"(pad16 -> DRCT-L + GRL-B + NAFNet-w64 + MambaIR -> fusion), batch 1",
+                           "lr_hw": [h, w], "images_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}",
+                           "small_experts": bool(args.small)},
+                "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            naf_cfg = dict(enc_blks=(1, 1, 1, 1), mid_blks=1, dec_blks=(1, 1, 1, 1)) if args.small else None
+            log("cpu_baseline: oracle on one 64x64 tile ...")
+            line["cpu_baseline"] = cpu_baseline(weights, naf_cfg)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

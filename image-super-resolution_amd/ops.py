@@ -17,6 +17,10 @@ from . import hip
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SILU = range(6)
 
+# bench.py sets this to a list to time every conv/GEMM launch with events on the launch stream:
+# entries (start_event, end_event, algorithmic flops = 2 * M * N * KH*KW*Cin with the UNPADDED Cin)
+CONV_PROFILE = None
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -85,6 +89,7 @@ class Conv:
     KW: int = 1
     stride: int = 1
     pad: int = 0
+    Cin_true: int = 0   # unpadded input channels (algorithmic flop accounting)
 
 
 def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
@@ -101,7 +106,7 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=
     if pad is None:
         pad = KH // 2
     return Conv(wp.reshape(N, KH * KW * Cp).contiguous().to(device),
-                None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride, pad)
+                None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride, pad, Cin)
 
 
 def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
@@ -128,9 +133,16 @@ def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[
     if akscale is not None:
         assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
         akrows = H * W
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     hip.call("ffsr_conv2d_f32", _ptr(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
              _ptr(akscale), B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad,
              act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true))
     return out
 
 

@@ -320,10 +320,10 @@ def fusion_state_dict(seed=5) -> SD:
 
 
 def random_weights(seed=0, small=False) -> Dict[str, SD]:
-    """All five state_dicts.  small=True: reduced-depth experts for smoke tests (same block types)."""
+    """All five state_dicts.  small=True: reduced-depth experts of the real width for smoke tests."""
     if small:
         return {"drct": drct_state_dict(seed + 1, groups=1), "grl": grl_state_dict(seed + 2, depths=(2,)),
-                "nafnet": nafnet_state_dict(seed + 3, width=16, enc=(1, 1, 1, 1), mid=1, dec=(1, 1, 1, 1)),
+                "nafnet": nafnet_state_dict(seed + 3, width=64, enc=(1, 1, 1, 1), mid=1, dec=(1, 1, 1, 1)),
                 "mamba": mambair_state_dict(seed + 4, depths=(1,)), "fusion": fusion_state_dict(seed + 5)}
     return {"drct": drct_state_dict(seed + 1), "grl": grl_state_dict(seed + 2), "nafnet": nafnet_state_dict(seed + 3),
             "mamba": mambair_state_dict(seed + 4), "fusion": fusion_state_dict(seed + 5)}

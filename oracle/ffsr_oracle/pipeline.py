@@ -29,7 +29,7 @@ def tensor2uint(t):
     return np.uint8((a * 255.0).round())
 
 
-def run_experts(weights, lr, scale=4, naf_cfg=None):
+def run_experts(weights, lr, scale=4, naf_cfg=None, scan_fn=None):
     """weights: dict drct/grl/nafnet/mamba -> state_dict.  Returns (imgs, feats, lr_in) like io._process_image."""
     lp, (h, w) = pad16(lr)
     imgs, feats = {}, {}
@@ -40,12 +40,12 @@ def run_experts(weights, lr, scale=4, naf_cfg=None):
     sr, f = nafnet.nafnet_sr(weights["nafnet"], lp, scale, **(naf_cfg or {}))
     imgs["nafnet"] = sr[:, :, :h * scale, :w * scale]
     feats["nafnet"] = F.interpolate(f, size=(h, w), mode="bilinear", align_corners=False)
-    sr, f = mambair.mambair_forward(weights["mamba"], lp)
+    sr, f = mambair.mambair_forward(weights["mamba"], lp, **({"scan_fn": scan_fn} if scan_fn else {}))
     imgs["mamba"], feats["mamba"] = sr.clamp(0, 1)[:, :, :h * scale, :w * scale], f[:, :, :h, :w]
     return imgs, feats, lp[:, :, :h, :w]
 
 
-def process_image(weights, lr, scale=4, naf_cfg=None):
+def process_image(weights, lr, scale=4, naf_cfg=None, scan_fn=None):
     """lr float [1,3,h,w] in [0,1] -> SR [1,3,4h,4w] in [0,1]."""
-    imgs, feats, lr_in = run_experts(weights, lr, scale, naf_cfg)
+    imgs, feats, lr_in = run_experts(weights, lr, scale, naf_cfg, scan_fn)
     return fusion.fusion_forward(weights["fusion"], lr_in, imgs, feats, scale)

@@ -87,3 +87,17 @@ def test_scan_matches_naive_loop():
             h = torch.exp(delta * A[d].double()) * h + delta * Bm[0, d // (Dm // G), :, t].double() * float(u[0, d, t])
             ref[0, d, t] = float((h * Cm[0, d // (Dm // G), :, t].double()).sum()) + float(D[d] * u[0, d, t])
     assert (y - ref).abs().max() < 1e-4
+
+
+def test_c_scan_matches_torch_scan():
+    from ffsr_oracle.scan import selective_scan_ref
+    from ffsr_oracle.scan_c import selective_scan_c
+    g = torch.Generator().manual_seed(1)
+    B, Dm, N, L, G = 2, 24, 16, 50, 4
+    u, dt = torch.randn(B, Dm, L, generator=g), torch.randn(B, Dm, L, generator=g)
+    A = -torch.rand(Dm, N, generator=g) - 0.1
+    Bm, Cm = torch.randn(B, G, N, L, generator=g), torch.randn(B, G, N, L, generator=g)
+    D, bias = torch.randn(Dm, generator=g), torch.randn(Dm, generator=g)
+    a = selective_scan_c(u, dt, A, Bm, Cm, D, delta_bias=bias, delta_softplus=True)
+    b = selective_scan_ref(u, dt, A, Bm, Cm, D, delta_bias=bias, delta_softplus=True)
+    assert (a - b).abs().max() < 1e-4
