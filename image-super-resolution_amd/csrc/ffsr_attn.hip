@@ -11,8 +11,8 @@
 namespace {
 
 // --------------------------------------------------------------------------------------------------------------
-// (1) DRCT window attention.  grid = (N/64 query blocks, heads, windows*B), 256 threads.
-// qkv: [B*H*W, ldq] with q at col h*hd, k at C + h*hd, v at 2C + h*hd.  bias: [heads, N, N] dense.
+// (1) DRCT window attention.  grid = (heads, windows*B), 256 threads.
+// qkv: [B*H*W, ldq] with q at col h*hd, k at C + h*hd, v at 2C + h*hd.  bias: [heads, N keys, N queries] dense.
 // --------------------------------------------------------------------------------------------------------------
 struct WinArgs {
   const float* qkv;
@@ -27,24 +27,26 @@ __device__ __forceinline__ int region_id(int p, int n, int ws, int shift) {
   return p < n - ws ? 0 : (p < n - shift ? 1 : 2);
 }
 
+// One workgroup (4 waves) per (window, head); each wave owns 64 queries.  Flash-style over 64-key tiles with the
+// product computed TRANSPOSED: S^T = K Q^T puts the query on the MFMA lane and the keys in the 16 accumulator
+// registers, so (a) the softmax row statistics are in-lane reductions plus one xor-32 exchange, and (b) the P^T tile
+// is already laid out as the B operand of O^T += V^T P^T -- probabilities never touch LDS.  Q fragments live in
+// registers; K / V tiles are staged through LDS once per workgroup.  biasT: [heads, N keys, N queries].
 template <int DT>  // DT = number of 32-wide head_dim tiles (hd <= 32*DT)
-__global__ __launch_bounds__(256) void window_attn_kernel(WinArgs p) {
+__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(WinArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int N = p.ws * p.ws;          // tokens per window (multiple of 64)
-  const int QS = p.hdp + 4;           // row stride of Q / KV tiles (floats); (hdp+4)/4 is odd
-  const int SS = N + 4;               // row stride of S
-  float* Qs = lds;                    // [64][QS]
-  float* KVs = Qs + 64 * QS;          // [64][QS]
-  float* Ss = KVs + 64 * QS;          // [64][SS]
-  int* tok_pix = reinterpret_cast<int*>(Ss + 64 * SS);  // [N] source pixel of every token of the window
-  int* tok_reg = tok_pix + N;                           // [N] mask region id
+  constexpr int NGMAX = 4 * DT;       // 8-wide k groups
+  const int N = p.ws * p.ws;          // tokens per window (256)
+  const int QS = p.hdp + 4;           // LDS row stride (floats); (hdp+4)/4 is odd -> b128 reads conflict-free
+  float* KV = lds;                    // [128][QS]: rows 0-63 K tile, 64-127 V tile (also Q staging) + 64 floats slack
+  int* tok_pix = reinterpret_cast<int*>(KV + 128 * QS + 64);  // [N]
+  int* tok_reg = tok_pix + N;                                  // [N]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qb = blockIdx.x, head = blockIdx.y;
+  const int head = blockIdx.x;
   const int nwx = p.W / p.ws, nwy = p.H / p.ws;
-  const int win = blockIdx.z % (nwx * nwy), b = blockIdx.z / (nwx * nwy);
+  const int win = blockIdx.y % (nwx * nwy), b = blockIdx.y / (nwx * nwy);
   const int wy = win / nwx, wx = win % nwx;
-
   for (int t = tid; t < N; t += 256) {
     int py = t / p.ws, px = t % p.ws;
     int ys = wy * p.ws + py, xs = wx * p.ws + px;  // position in the rolled image
@@ -54,120 +56,122 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs p) {
     tok_pix[t] = (b * p.H + y) * p.W + x;
     tok_reg[t] = p.masked ? region_id(ys, p.H, p.ws, p.shift) * 3 + region_id(xs, p.W, p.ws, p.shift) : 0;
   }
-  __syncthreads();
-
-  const int hd = p.hd, hdp = p.hdp;
-  // ---- Q block (scaled), zero padded to hdp
-  for (int i = tid; i < 64 * hdp; i += 256) {
-    int r = i / hdp, d = i - r * hdp;
-    float v = 0.f;
-    if (d < hd) v = p.qkv[(size_t)tok_pix[qb * 64 + r] * p.ldq + head * hd + d] * p.scale;
-    Qs[r * QS + d] = v;
-  }
-
+  const int hd = p.hd, hdp = p.hdp, ng = hdp >> 3;
   const int r32 = lane & 31, hh = lane >> 5;
-  const int trow = (wave >> 1) * 32, tcol = (wave & 1) * 32;  // this wave's 32x32 tile of the 64x64 S block
-  // ---- S = Q K^T, one 64-key tile at a time
-  for (int kt = 0; kt < N / 64; ++kt) {
-    __syncthreads();  // previous tile consumed (and Q written, first iteration)
-    for (int i = tid; i < 64 * hdp; i += 256) {
-      int r = i / hdp, d = i - r * hdp;
-      float v = 0.f;
-      if (d < hd) v = p.qkv[(size_t)tok_pix[kt * 64 + r] * p.ldq + p.C + head * hd + d];
-      KVs[r * QS + d] = v;
+  const float* qbase = p.qkv + head * hd;
+
+  // ---- Q fragments -> registers (staged through LDS, 128 tokens per round)
+  floatx4 qf[2][NGMAX];
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();
+    for (int rr = wave; rr < 128; rr += 4) {
+      const float* src = qbase + (size_t)tok_pix[round * 128 + rr] * p.ldq;
+      for (int d = lane; d < hdp; d += 64) KV[rr * QS + d] = d < hd ? src[d] * p.scale : 0.f;
     }
     __syncthreads();
-    floatx16 acc;
+    if ((wave >> 1) == round) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k8 = 0; k8 < hdp; k8 += 8) {
-      floatx4 a = *reinterpret_cast<const floatx4*>(Qs + (trow + r32) * QS + k8 + 4 * hh);
-      floatx4 bb = *reinterpret_cast<const floatx4*>(KVs + (tcol + r32) * QS + k8 + 4 * hh);
+      for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bb[s], acc, 0, 0, 0);
-    }
-    // + bias (+ mask) -> S
-    const int key = kt * 64 + tcol + r32;
-    const int kreg = tok_reg[key];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int qr = trow + (e & 3) + 8 * (e >> 2) + 4 * hh;
-      int q = qb * 64 + qr;
-      float v = acc[e] + p.bias[((size_t)head * N + q) * N + key];
-      if (p.masked && tok_reg[q] != kreg) v += -100.0f;
-      Ss[qr * SS + key] = v;
+        for (int j = 0; j < NGMAX; ++j)
+          if (j < ng) qf[qt][j] = *reinterpret_cast<const floatx4*>(KV + ((wave & 1) * 64 + qt * 32 + r32) * QS + 8 * j + 4 * hh);
     }
   }
-  __syncthreads();
-  // ---- row softmax: wave handles 16 rows, lane holds N/64 columns
-  for (int rr = 0; rr < 16; ++rr) {
-    float* row = Ss + (wave * 16 + rr) * SS;
-    float v[4];
-    float m = -3.0e38f;
+  int qreg[2];
+  qreg[0] = tok_reg[wave * 64 + r32];
+  qreg[1] = tok_reg[wave * 64 + 32 + r32];
+
+  floatx16 o[DT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int c = lane + 64 * i;
-      v[i] = c < N ? row[c] : -3.0e38f;
-      m = fmaxf(m, v[i]);
-    }
-    m = wave_max(m);
-    float s = 0.f;
+  for (int i = 0; i < DT; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i] = (lane + 64 * i < N) ? expf(v[i] - m) : 0.f;
-      s += v[i];
-    }
-    s = 1.0f / wave_sum(s);
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (lane + 64 * i < N) row[lane + 64 * i] = v[i] * s;
-  }
-  // ---- O = P V : 2 row tiles x DT column tiles over 4 waves
-  constexpr int NT = (DT + 1) / 2;  // column tiles per wave
-  floatx16 o[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-  const int orow = (wave & 1) * 32;
+      for (int e = 0; e < 16; ++e) o[i][q][e] = 0.f;
+  float mrow[2] = {-3.0e38f, -3.0e38f}, lrow[2] = {0.f, 0.f};
+  const float* bias_h = p.bias + (size_t)head * N * N;
+
+#pragma unroll 1
   for (int kt = 0; kt < N / 64; ++kt) {
-    __syncthreads();
-    for (int i = tid; i < 64 * hdp; i += 256) {
-      int r = i / hdp, d = i - r * hdp;
-      float v = 0.f;
-      if (d < hd) v = p.qkv[(size_t)tok_pix[kt * 64 + r] * p.ldq + 2 * p.C + head * hd + d];
-      KVs[r * QS + d] = v;
+    __syncthreads();  // previous tile fully consumed
+    for (int rr = wave; rr < 64; rr += 4) {
+      const float* src = qbase + (size_t)tok_pix[kt * 64 + rr] * p.ldq + p.C;
+      for (int d = lane; d < hdp; d += 64) {
+        const bool ok = d < hd;
+        KV[rr * QS + d] = ok ? src[d] : 0.f;                 // K
+        KV[(64 + rr) * QS + d] = ok ? src[p.C + d] : 0.f;    // V
+      }
     }
-    // columns hdp .. 32*DT of the V tile are never read with d >= hdp unguarded (see below)
     __syncthreads();
-    for (int k8 = 0; k8 < 64; k8 += 8) {
-      floatx4 a = *reinterpret_cast<const floatx4*>(Ss + (orow + r32) * SS + kt * 64 + k8 + 4 * hh);
+#pragma unroll 1
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* Kt = KV + (ks * 32) * QS;
+      const float* Vt = KV + (64 + ks * 32) * QS;
+      const int key0 = kt * 64 + ks * 32 + 4 * hh;  // + (e&3) + 8*(e>>2)
+      floatx16 s[2];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int ct = (wave >> 1) + 2 * i;
-        if (ct < DT) {
-          const int d = ct * 32 + r32;
+      for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            float bv = d < hdp ? KVs[(k8 + 4 * hh + s) * QS + d] : 0.f;
-            o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, o[i], 0, 0, 0);
+        for (int e = 0; e < 16; ++e) s[qt][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NGMAX; ++j) {
+          if (j < ng) {
+            const floatx4 a = *reinterpret_cast<const floatx4*>(Kt + r32 * QS + 8 * j + 4 * hh);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], qf[qt][j][t], s[qt], 0, 0, 0);
           }
+        }
+        const int q = wave * 64 + qt * 32 + r32;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + (e & 3) + 8 * (e >> 2);
+          float v = s[qt][e] + bias_h[(size_t)key * N + q];
+          if (p.masked && tok_reg[key] != qreg[qt]) v += -100.0f;
+          s[qt][e] = v;
+          mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrow[qt], mx);
+        const float corr = __expf(mrow[qt] - mnew);
+        mrow[qt] = mnew;
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          s[qt][e] = __expf(s[qt][e] - mnew);
+          ps += s[qt][e];
+        }
+        lrow[qt] = lrow[qt] * corr + ps;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][qt][e] *= corr;
+      }
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        float vv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) vv[e] = Vt[((e & 3) + 8 * (e >> 2) + 4 * hh) * QS + i * 32 + r32];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          o[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], s[0][e], o[i][0], 0, 0, 0);
+          o[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], s[1][e], o[i][1], 0, 0, 0);
         }
       }
     }
   }
-  // ---- store: col = d on the lane, rows = queries
+  // ---- normalise and store O^T: lane = query, registers = head-dim rows
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int ct = (wave >> 1) + 2 * i;
-    const int d = ct * 32 + r32;
-    if (ct < DT && d < hd) {
+  for (int qt = 0; qt < 2; ++qt) {
+    const float inv = 1.0f / (lrow[qt] + __shfl_xor(lrow[qt], 32, 64));
+    float* orow = p.out + (size_t)tok_pix[wave * 64 + qt * 32 + r32] * p.ldo + head * hd;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        int qr = orow + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        p.out[(size_t)tok_pix[qb * 64 + qr] * p.ldo + head * hd + d] = o[i][e];
+        const int d = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (d < hd) orow[d] = o[i][qt][e] * inv;
       }
-    }
   }
 }
 
@@ -442,10 +446,11 @@ extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias
   a.qkv = qkv; a.bias = bias; a.out = out; a.ldq = ldq; a.ldo = ldo; a.C = C; a.H = H; a.W = W; a.ws = ws;
   a.shift = shift; a.heads = heads; a.hd = hd; a.hdp = (hd + 7) / 8 * 8; a.masked = shift > 0; a.scale = scale;
   const int N = ws * ws;
-  const size_t lds = (size_t)(2 * 64 * (a.hdp + 4) + 64 * (N + 4)) * 4 + 2 * N * 4;
+  FFSR_CHECK(N == 256);
+  const size_t lds = (size_t)(128 * (a.hdp + 4) + 64) * 4 + 2 * N * 4;
   FFSR_CHECK(lds <= 160 * 1024);
-  dim3 grid(N / 64, heads, (H / ws) * (W / ws) * B);
-  FFSR_CHECK(grid.z <= 65535);
+  dim3 grid(heads, (H / ws) * (W / ws) * B);
+  FFSR_CHECK(grid.y <= 65535);
   const int DT = (hd + 31) / 32;
 #define LAUNCH_WIN(D)                                                                                            \
   {                                                                                                              \

@@ -155,14 +155,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[((size_t)b * nchunk + chunk) * C + c] = s;
   }
 }
-__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C, int nchunk,
-                                     float scale) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * C) return;
-  int b = idx / C, c = idx - b * C;
+// out[b, c] = scale * sum_k part[b, k, c]; grid = (ceil(C/64), B), block 256 = 64 channels x 4 chunk lanes
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C,
+                                                            int nchunk, float scale) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int kl = threadIdx.x >> 6, b = blockIdx.y;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * C + c];
-  out[idx] = s * scale;
+  if (c < C)
+    for (int k = kl; k < nchunk; k += 4) s += part[((size_t)b * nchunk + k) * C + c];
+  red[kl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (kl == 0 && c < C)
+    out[(size_t)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale;
 }
 
 // ------------------------------------------------------------------------------------------- depthwise conv
@@ -467,8 +472,7 @@ extern "C" int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part
                                 void* stream) {
   FFSR_CHECK(x && out && part && B > 0 && R > 0 && C > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0, ST, part, out, B, C, nchunk,
-                     1.0f / (float)R);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(256), 0, ST, part, out, B, C, nchunk, 1.0f / (float)R);
   return ffsr_launch_status();
 }
 
@@ -491,7 +495,7 @@ extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w
   FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
   hipLaunchKernelGGL(dw3x3_gate_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part, H,
                      W, C, nchunk);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0, ST, part, pooled, B, C, nchunk,
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(256), 0, ST, part, pooled, B, C, nchunk,
                      1.0f / (float)(H * W));
   return ffsr_launch_status();
 }

@@ -43,18 +43,23 @@ __device__ __forceinline__ int tok_pixel(int k, int t, int H, int W, int L) {
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// Steps are processed in groups of G: the group's u values (registers) and projection rows (LDS, wave-uniform reads)
+// are fetched one group ahead, so the recurrence never waits on HBM latency.
 template <int R, bool EMIT>
 __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs p) {
-  const int d = blockIdx.x * 64 + threadIdx.x;
+  constexpr int G = 8, XW = R + 2 * NS, XN = (G * XW + 63) / 64;
+  __shared__ float xs[2][G * XW];
+  const int lane = threadIdx.x;
+  const int d = blockIdx.x * 64 + lane;
   const int c = blockIdx.y;
   const int k = blockIdx.z & 3, b = blockIdx.z >> 2;
   const bool live = d < p.Dm;
   const int dd = live ? d : p.Dm - 1;
-  float w[R], a[NS], h[NS];
+  float w[R], a2[NS], h[NS];
 #pragma unroll
   for (int r = 0; r < R; ++r) w[r] = p.dtw[((size_t)k * p.Dm + dd) * R + r];
 #pragma unroll
-  for (int n = 0; n < NS; ++n) a[n] = p.A[((size_t)k * p.Dm + dd) * NS + n];
+  for (int n = 0; n < NS; ++n) a2[n] = p.A[((size_t)k * p.Dm + dd) * NS + n] * 1.4426950408889634f;  // exp(x) = 2^(x log2 e)
   const float bias = p.dtb[k * p.Dm + dd];
   const float dskip = p.Dv[k * p.Dm + dd];
   const size_t sidx = ((((size_t)b * 4 + k) * p.nchunk + c) * p.Dm + dd) * NS;
@@ -63,35 +68,77 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs p) {
   float dsum = 0.f;
   const int t0 = c * p.chunk, t1 = min(p.L, t0 + p.chunk);
   const float* ub = p.u + (size_t)b * p.L * p.ldu;
-  const float* xb = p.xdbl + (size_t)b * p.L * p.ldx + k * (R + 2 * NS);
+  const float* xb = p.xdbl + (size_t)b * p.L * p.ldx + k * XW;
   float* yb = p.y + ((size_t)k * p.B + b) * p.L * p.ldy;
-  for (int t = t0; t < t1; ++t) {
-    const int pix = tok_pixel(k, t, p.H, p.W, p.L);
-    const float* xr = xb + (size_t)pix * p.ldx;  // wave-uniform row
-    const float uu = ub[(size_t)pix * p.ldu + dd];
-    float dt = bias;
+
+  float u_cur[G], u_nxt[G], x_nxt[XN];
+  int pix_cur[G], pix_nxt[G];
+  auto fetch = [&](int tg) {  // global -> registers for the group starting at step tg
+    const int mypix = tok_pixel(k, min(tg + (lane & (G - 1)), p.L - 1), p.H, p.W, p.L);
 #pragma unroll
-    for (int r = 0; r < R; ++r) dt = fmaf(w[r], xr[r], dt);
-    const float delta = softplus_f(dt);
-    const float du = delta * uu;
-    float yv = 0.f;
+    for (int r = 0; r < G; ++r) {
+      pix_nxt[r] = __shfl(mypix, r, 64);
+      u_nxt[r] = ub[(size_t)pix_nxt[r] * p.ldu + dd];
+    }
 #pragma unroll
-    for (int n = 0; n < NS; ++n) {
-      const float dA = expf(delta * a[n]);
-      h[n] = fmaf(dA, h[n], du * xr[R + n]);
-      if (EMIT) yv = fmaf(xr[R + NS + n], h[n], yv);
+    for (int i = 0; i < XN; ++i) {
+      const int idx = lane + 64 * i;
+      const int row = idx / XW, col = idx - row * XW;
+      const int rp = __shfl(mypix, row & (G - 1), 64);
+      x_nxt[i] = idx < G * XW ? xb[(size_t)rp * p.ldx + col] : 0.f;
     }
-    if (EMIT) {
-      if (live) yb[(size_t)pix * p.ldy + d] = fmaf(dskip, uu, yv);
-    } else {
-      dsum += delta;
+  };
+  auto commit = [&](int buf) {  // registers -> LDS / current
+#pragma unroll
+    for (int i = 0; i < XN; ++i)
+      if (lane + 64 * i < G * XW) xs[buf][lane + 64 * i] = x_nxt[i];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      u_cur[r] = u_nxt[r];
+      pix_cur[r] = pix_nxt[r];
     }
+  };
+  fetch(t0);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int tg = t0; tg < t1; tg += G) {
+    const bool more = tg + G < t1;
+    if (more) fetch(tg + G);
+    const float* xg = xs[buf];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      if (tg + r < t1) {
+        const float* xr = xg + r * XW;  // wave-uniform LDS reads (broadcast)
+        const float uu = u_cur[r];
+        float dt = bias;
+#pragma unroll
+        for (int q = 0; q < R; ++q) dt = fmaf(w[q], xr[q], dt);
+        const float delta = softplus_f(dt);
+        const float du = delta * uu;
+        float yv = 0.f;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+          const float dA = __builtin_amdgcn_exp2f(delta * a2[n]);
+          h[n] = fmaf(dA, h[n], du * xr[R + n]);
+          if (EMIT) yv = fmaf(xr[R + NS + n], h[n], yv);
+        }
+        if (EMIT) {
+          if (live) yb[(size_t)pix_cur[r] * p.ldy + d] = fmaf(dskip, uu, yv);
+        } else {
+          dsum += delta;
+        }
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
   if (!EMIT && live) {
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
       p.hstate[sidx + n] = h[n];
-      p.decay[sidx + n] = expf(a[n] * dsum);
+      p.decay[sidx + n] = __builtin_amdgcn_exp2f(a2[n] * dsum);
     }
   }
 }

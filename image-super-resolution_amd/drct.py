@@ -29,7 +29,7 @@ class _Swin:
         self.fc2 = ops.pack_conv(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], device)
         N = ws * ws
         table = sd[p + "attn.relative_position_bias_table"].float()
-        self.bias = dev(table[_rel_index(ws)].reshape(N, N, heads).permute(2, 0, 1), device)   # [heads, N, N]
+        self.bias = dev(table[_rel_index(ws)].reshape(N, N, heads).permute(2, 1, 0), device)   # [heads, keys, queries]
         self.scale = (dim // heads) ** -0.5
 
     def __call__(self, x, B, H, W):

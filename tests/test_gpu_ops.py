@@ -169,7 +169,7 @@ def test_window_attn(ops, C, heads, shift, H, W):
     o = win_merge((a.softmax(-1) @ w[2]).transpose(1, 2).reshape(-1, 256, C), ws, ws, H, W)
     if shift:
         o = torch.roll(o, (shift, shift), (1, 2))
-    got = ops.window_attn(qkv.to(DEV), bias.to(DEV), B, H, W, C, heads, ws, shift, hd ** -0.5)
+    got = ops.window_attn(qkv.to(DEV), bias.transpose(1, 2).contiguous().to(DEV), B, H, W, C, heads, ws, shift, hd ** -0.5)
     close(got.cpu(), o.reshape(B * H * W, C), 2e-5, "window attention")
 
 
