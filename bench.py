@@ -128,8 +128,8 @@ def main():
     eng.process(lrs[0])
     torch.cuda.synchronize(device)
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    dur_ms = [a.elapsed_time(b) for a, b, _ in prof]
-    flops = sum(f for _, _, f in prof)
+    dur_ms = [a.elapsed_time(b) for a, b, _, _ in prof]
+    flops = sum(f for _, _, f, _ in prof)
     conv_s = sum(dur_ms) / 1e3
     t1 = time.perf_counter()
     eng.process(lrs[0])
@@ -138,6 +138,12 @@ def main():
     achieved = flops / conv_s / 1e12
     # per-expert split of one step (diagnostic, stderr only)
     if rank == 0:
+        by_shape = {}
+        for (e0, e1, f, shape), ms in zip(prof, dur_ms):
+            t = by_shape.setdefault(shape, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += ms; t[2] += f
+        for shape, (n, ms, f) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:14]:
+            log(f"  conv M={shape[0]:8d} N={shape[1]:4d} K={shape[2]:5d} k{shape[3]} x{n:4d}: {ms:7.1f} ms {f / ms / 1e9:6.1f} TFLOP/s")
         lp = ops.pad_reflect(lrs[0], (h + 15) // 16 * 16, (w + 15) // 16 * 16)
         for name, fn in (("drct", eng.drct), ("grl", eng.grl), ("nafnet", eng.nafnet), ("mamba", eng.mamba)):
             torch.cuda.synchronize(device)

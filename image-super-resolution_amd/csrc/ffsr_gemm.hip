@@ -38,13 +38,13 @@ struct ConvArgs {
   int M, Ktot, akrows;  // akrows = rows (pixels) per akscale batch
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_AK, int STAGES>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread in the loaders
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LSTR];
+  __shared__ __attribute__((aligned(16))) float smem[STAGES][(BM + BN) * LSTR];
 
   // ---- XCD-aware tile id (bijective for any grid size)
   const int nwg = gridDim.x;
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   }
 
   floatx4 a_reg[AR], b_reg[BR];
+  float a_ok[AR], b_ok[BR];  // 1.0 / 0.0 masks (see load_tiles)
   const bool is1x1 = (p.KH * p.KW == 1);
 
   auto load_tiles = [&](int kt) {
@@ -92,37 +93,42 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
       ky = tap / p.KW;
       kx = tap - ky * p.KW;
     }
+    // NOTE: every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards by a
+    // MULTIPLY with a 0/1 mask: a load under `if (ok)` -- or a select the compiler can sink the load into -- makes
+    // hipcc branch around it and wait vmcnt(0) per load, which serialises the whole prefetch
+    // (cdna_hip_programming.md section 5, trap (c)).  Clamped reads hit offset 0 of a live tensor (finite data).
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      int yy = a_iy0[i] + ky, xx = a_ix0[i] + kx;
-      bool ok = kval && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        size_t off = (size_t)(a_pix[i] + yy * p.W + xx) * p.ldi + ci;
-        v = *reinterpret_cast<const floatx4*>(p.in + off);
-        if (p.akscale) {
-          int m = m0 + rbase + 32 * i;
-          const floatx4 s = *reinterpret_cast<const floatx4*>(p.akscale + (size_t)(m / p.akrows) * p.Ktot + k);
-          v *= s;
-        }
+      const int yy = a_iy0[i] + ky, xx = a_ix0[i] + kx;
+      const bool ok = kval && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      a_ok[i] = ok ? 1.f : 0.f;
+      const size_t off = ok ? (size_t)(a_pix[i] + yy * p.W + xx) * p.ldi + ci : 0;
+      a_reg[i] = *reinterpret_cast<const floatx4*>(p.in + off);
+    }
+    if (HAS_AK) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int m = min(m0 + rbase + 32 * i, p.M - 1);
+        const size_t off = (size_t)(m / p.akrows) * p.Ktot + (kval ? k : 0);
+        a_reg[i] *= *reinterpret_cast<const floatx4*>(p.akscale + off);
       }
-      a_reg[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      int n = n0 + rbase + 32 * i;
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kval && n < p.N) v = *reinterpret_cast<const floatx4*>(p.wgt + (size_t)n * p.ldw + k);
-      b_reg[i] = v;
+      const int n = n0 + rbase + 32 * i;
+      const bool ok = kval && n < p.N;
+      b_ok[i] = ok ? 1.f : 0.f;
+      const size_t off = ok ? (size_t)n * p.ldw + k : 0;
+      b_reg[i] = *reinterpret_cast<const floatx4*>(p.wgt + off);
     }
   };
   auto store_tiles = [&](int buf) {
     float* As = smem[buf];
     float* Bs = As + BM * LSTR;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<floatx4*>(As + (rbase + 32 * i) * LSTR + kofs) = a_reg[i];
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<floatx4*>(As + (rbase + 32 * i) * LSTR + kofs) = a_reg[i] * a_ok[i];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<floatx4*>(Bs + (rbase + 32 * i) * LSTR + kofs) = b_reg[i];
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<floatx4*>(Bs + (rbase + 32 * i) * LSTR + kofs) = b_reg[i] * b_ok[i];
   };
 
   floatx16 acc[TM][TN];
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tiles(kt + 1);
-    const float* As = smem[kt & 1];
+    const float* As = smem[STAGES == 2 ? (kt & 1) : 0];
     const float* Bs = As + BM * LSTR;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -161,7 +167,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
           for (int jj = 0; jj < TN; ++jj)
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[jj][s], acc[i][jj], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+    if (STAGES == 1) __syncthreads();  // all waves done reading the single buffer
+    if (kt + 1 < nk) store_tiles(STAGES == 2 ? ((kt + 1) & 1) : 0);
     __syncthreads();
   }
 
@@ -197,10 +204,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 int launch(const ConvArgs& a, hipStream_t st) {
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(tiles), dim3(256), 0, st, a);
+  if (a.akscale)
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, STAGES>), dim3(tiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, STAGES>), dim3(tiles), dim3(256), 0, st, a);
   return ffsr_launch_status();
 }
 
@@ -231,21 +241,24 @@ extern "C" int ffsr_conv2d_f32(const float* in, const float* wgt, const float* b
   FFSR_CHECK(M < (1ll << 31) && (long long)B * H * W < (1ll << 31));
   a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
-  // tile choice: minimise padded columns; tile_hint overrides (1: 128x128, 2: 128x64, 3: 256x32, 4: 64x64)
+  // tile choice (measured with tools/gemm_bench.py on MI355X): the 128x64 tile with ONE LDS stage (27 KB -> 4
+  // workgroups per CU) beats the double-buffered tiles on every shape of this path; 256x32 serves N <= 32 and
+  // 64x64 the tiny [B, C] channel-attention GEMMs.  tile_hint overrides (1/2/3/4 double-buffered 128x128 / 128x64 /
+  // 256x32 / 64x64; 11/12/13 their single-stage forms).
   int choice = tile_hint;
   if (choice == 0) {
-    if (N <= 32) choice = 3;
-    else {
-      int w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
-      choice = (w128 == w64) ? 1 : 2;
-    }
+    if (N <= 32) choice = 13;
+    else choice = 12;
     if (a.M <= 64 * 24 && N > 32) choice = 4;
   }
   switch (choice) {
-    case 1: return launch<128, 128, 2, 2>(a, st);
-    case 2: return launch<128, 64, 2, 2>(a, st);
-    case 3: return launch<256, 32, 4, 1>(a, st);
-    case 4: return launch<64, 64, 2, 2>(a, st);
+    case 1: return launch<128, 128, 2, 2, 2>(a, st);
+    case 2: return launch<128, 64, 2, 2, 2>(a, st);
+    case 3: return launch<256, 32, 4, 1, 2>(a, st);
+    case 4: return launch<64, 64, 2, 2, 2>(a, st);
+    case 11: return launch<128, 128, 2, 2, 1>(a, st);   // single LDS stage: more workgroups per CU
+    case 12: return launch<128, 64, 2, 2, 1>(a, st);
+    case 13: return launch<256, 32, 4, 1, 1>(a, st);
     default: return FFSR_EINVAL;
   }
 }

@@ -142,7 +142,8 @@ def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[
              act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true))
+        prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true,
+                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH)))
     return out
 
 
@@ -222,6 +223,10 @@ def _nchunk(R: int) -> int:
     return max(1, min(256, R // 256))
 
 
+def _nchunk_gate(R: int) -> int:
+    return max(1, min(4096, R // 128))
+
+
 def colmean(x: torch.Tensor) -> torch.Tensor:
     """[B,H,W,C] -> [B,C] spatial mean."""
     B, H, W, C = x.shape
@@ -264,7 +269,7 @@ def dw3x3_gate_pool(x, dw: DwConv):
     B, H, W, C2 = x.shape
     C = C2 // 2
     out = new_map(B, H, W, C, x.device)
-    n = _nchunk(H * W)
+    n = _nchunk_gate(H * W)
     part = torch.empty(B, n, C, device=x.device)
     pooled = torch.empty(B, C, device=x.device)
     hip.call("ffsr_dw3x3_gate_pool_f32", _ptr(x), ld(x), _ptr(dw.w), _ptr(dw.bias), _ptr(out), ld(out), _ptr(pooled),
