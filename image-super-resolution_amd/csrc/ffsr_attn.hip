@@ -62,12 +62,42 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
 
   // ---- Q fragments -> registers (staged through LDS, 128 tokens per round)
   floatx4 qf[2][NGMAX];
+  // tile loader: rows wave, wave+4, ... of a 64-row tile; all global loads of a batch are issued before any LDS
+  // store (unconditional, clamped column + 0/1 mask: a load under a branch would be waited for one by one)
+  constexpr int DI = DT > 2 ? 2 : 1;   // 64-lane column passes per row (hd <= 64 * DI)
+  constexpr int RB = DT == 1 ? 8 : 4;  // rows per batch per wave (register budget)
+  float cmask[DI];
+  int ccol[DI];
+#pragma unroll
+  for (int di = 0; di < DI; ++di) {
+    const int d = lane + 64 * di;
+    cmask[di] = d < hd ? 1.f : 0.f;
+    ccol[di] = min(d, hd - 1);
+  }
+  auto load_rows = [&](int tok0, int col0, float scale, float* dst) {   // 64 tokens tok0.. -> dst[64][QS]
+#pragma unroll 1
+    for (int batch = 0; batch < 16 / RB; ++batch) {
+      float reg[RB][DI];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int rr = wave + 4 * (batch * RB + r);
+        const float* src = qbase + (size_t)tok_pix[tok0 + rr] * p.ldq + col0;
+#pragma unroll
+        for (int di = 0; di < DI; ++di) reg[r][di] = src[ccol[di]];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int rr = wave + 4 * (batch * RB + r);
+#pragma unroll
+        for (int di = 0; di < DI; ++di)
+          if (lane + 64 * di < hdp) dst[rr * QS + lane + 64 * di] = reg[r][di] * cmask[di] * scale;
+      }
+    }
+  };
   for (int round = 0; round < 2; ++round) {
     __syncthreads();
-    for (int rr = wave; rr < 128; rr += 4) {
-      const float* src = qbase + (size_t)tok_pix[round * 128 + rr] * p.ldq;
-      for (int d = lane; d < hdp; d += 64) KV[rr * QS + d] = d < hd ? src[d] * p.scale : 0.f;
-    }
+    load_rows(round * 128, 0, p.scale, KV);
+    load_rows(round * 128 + 64, 0, p.scale, KV + 64 * QS);
     __syncthreads();
     if ((wave >> 1) == round) {
 #pragma unroll
@@ -94,14 +124,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
 #pragma unroll 1
   for (int kt = 0; kt < N / 64; ++kt) {
     __syncthreads();  // previous tile fully consumed
-    for (int rr = wave; rr < 64; rr += 4) {
-      const float* src = qbase + (size_t)tok_pix[kt * 64 + rr] * p.ldq + p.C;
-      for (int d = lane; d < hdp; d += 64) {
-        const bool ok = d < hd;
-        KV[rr * QS + d] = ok ? src[d] : 0.f;                 // K
-        KV[(64 + rr) * QS + d] = ok ? src[p.C + d] : 0.f;    // V
-      }
-    }
+    load_rows(kt * 64, p.C, 1.0f, KV);                // K tile
+    load_rows(kt * 64, 2 * p.C, 1.0f, KV + 64 * QS);  // V tile
     __syncthreads();
 #pragma unroll 1
     for (int ks = 0; ks < 2; ++ks) {

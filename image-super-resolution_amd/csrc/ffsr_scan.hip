@@ -41,7 +41,15 @@ __device__ __forceinline__ int tok_pixel(int k, int t, int H, int W, int L) {
   return t;
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// softplus with torch's threshold 20, on the hardware exp2/log2: log1p(e) = e(1 - e(1/2 - e/3)) for small e = exp(x)
+// (relative error < 4e-7), log(1 + e) otherwise.  Branch-free selects.
+__device__ __forceinline__ float softplus_f(float x) {
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.4426950408889634f);
+  const float small = e * (1.f - e * (0.5f - e * 0.33333334f));
+  const float big = __builtin_amdgcn_logf(1.f + e) * 0.6931471805599453f;
+  const float sp = e < 0.01f ? small : big;
+  return x > 20.f ? x : sp;
+}
 
 // Steps are processed in groups of G: the group's u values (registers) and projection rows (LDS, wave-uniform reads)
 // are fetched one group ahead, so the recurrence never waits on HBM latency.

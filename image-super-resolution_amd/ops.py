@@ -332,8 +332,12 @@ def pixel_mha(qkv, S, T, E, heads, out=None):
 
 
 def scan_chunk(L: int) -> int:
-    """Chunk length of the 3-pass scan: enough chunks to fill 256 CUs, at least 32 steps each."""
-    return int(min(1024, max(32, 2 ** math.ceil(math.log2(max(1, L / 256))))))
+    """Chunk length of the 3-pass scan: ~512 chunks x 24 waves keeps every SIMD several waves deep (load balance),
+    at least 32 steps per chunk."""
+    c = 32
+    while c * 2 <= min(1024, L // 512):
+        c *= 2
+    return c
 
 
 def selective_scan4(u, xdbl, dtw, dtb, A, Dv, B, H, W, Dm, R, chunk=None):
