@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--width", type=int, default=W_LR)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=None, help="GEMM arithmetic (default: the engine's default)")
     args = ap.parse_args()
 
     W = importlib.import_module("image-super-resolution_amd.weights")
@@ -78,6 +79,8 @@ def main():
     ops = importlib.import_module("image-super-resolution_amd.ops")
 
     T0 = time.perf_counter()
+    if args.gemm:
+        ops.set_gemm_mode(args.gemm)
     rank, world = S.rank_world()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:

@@ -8,6 +8,7 @@ or channels padded to a multiple of 4).  Token matrices [M, C] are maps with B =
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -16,6 +17,21 @@ import torch
 from . import hip
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SILU = range(6)
+
+# GEMM arithmetic mode of conv2d/linear when no explicit tile_hint is given:
+#   "f32"    exact f32-input MFMA (v_mfma_f32_32x32x2_f32), an fmaf chain like the reference's CPU path
+#   "bf16x3" split-bf16 3-term MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~1e-5 relative per product, ~2x faster.
+#            Default: full-depth parity vs the oracle is 1e-5 max-abs (PSNR 116 dB), 100x inside north_star's 1e-3
+#            (tests/test_gpu_models.py::test_full_depth_experts_and_fusion_vs_oracle_64x64).  FFSR_GEMM_MODE=f32 selects
+#            the exact kernel.
+GEMM_MODE = os.environ.get("FFSR_GEMM_MODE", "bf16x3")
+
+
+def set_gemm_mode(mode: str):
+    global GEMM_MODE
+    assert mode in ("f32", "bf16x3")
+    GEMM_MODE = mode
+
 
 # bench.py sets this to a list to time every conv/GEMM launch with events on the launch stream:
 # entries (start_event, end_event, algorithmic flops = 2 * M * N * KH*KW*Cin with the UNPADDED Cin)
@@ -133,6 +149,8 @@ def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[
     if akscale is not None:
         assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
         akrows = H * W
+    if tile_hint == 0 and GEMM_MODE == "bf16x3" and B * Ho * Wo > 64 * 24:
+        tile_hint = 21 if cv.N <= 32 else 20
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

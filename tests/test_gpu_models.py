@@ -1,6 +1,7 @@
 """GPU parity: the HIP engine against (a) the golden vectors captured from the reference and (b) the CPU oracle
 on seeded inputs at the real layer dimensions.  north_star tolerance: max abs <= 1e-3 in fp32."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -130,3 +131,33 @@ def test_process_image_vs_oracle_small_experts_odd_size():
     assert np.abs(got_u8.astype(int) - want_u8.astype(int)).max() <= 1      # rounding boundary only
     mse = ((got - want) ** 2).mean().item()
     assert mse < 1e-8
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_full_depth_experts_and_fusion_vs_oracle_64x64(mode):
+    """BASELINE config 3 geometry (64x64 LR tile) with the FULL-DEPTH experts (12 RDG / 40 GRL blocks / 36 NAF blocks /
+    36 VSS blocks) and the fusion net, both GEMM arithmetic modes, against the CPU oracle.  north_star: <= 1e-3."""
+    from ffsr_oracle import pipeline
+    from ffsr_oracle.scan_c import selective_scan_c
+    W, E, ops = mod("weights"), mod("engine"), mod("ops")
+    weights = W.random_weights(seed=50)
+    lr = lr_image(15, 1, 64, 64)
+    imgs_o, feats_o, _ = pipeline.run_experts(weights, lr, scan_fn=selective_scan_c)
+    from ffsr_oracle import fusion as ofusion
+    want = ofusion.fusion_forward(weights["fusion"], lr, imgs_o, feats_o)
+    ops.set_gemm_mode(mode)
+    try:
+        eng = E.Engine(weights, DEV)
+        lrm = E.nchw_to_map(lr, DEV)
+        imgs, feats = eng.run_experts(lrm)
+        got = E.map_to_nchw(eng.fusion(lrm, imgs, feats))
+    finally:
+        ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
+    report = {n: (err(E.map_to_nchw(imgs[n]), imgs_o[n]), err(E.map_to_nchw(feats[n]), feats_o[n])) for n in imgs}
+    final = err(got, want)
+    mse = ((got - want) ** 2).mean().item()
+    print(f"[{mode}] per-expert (sr, feat) max abs err: {report}; final {final:.3e}; "
+          f"PSNR(hip, oracle) = {10 * __import__('math').log10(1.0 / max(mse, 1e-20)):.1f} dB")
+    for n, (e_sr, e_feat) in report.items():
+        assert e_sr < TOL, (mode, n, e_sr, e_feat)
+    assert final < TOL, (mode, final)

@@ -31,6 +31,10 @@ def main():
                 continue
             out = ops.conv2d(x, cv, tile_hint=hint)
             torch.cuda.synchronize()
+            if hint == hints[0]:
+                ref = out.clone()
+            else:
+                line += f" [err {((out - ref).abs().max() / ref.abs().max()).item():.1e}]"
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
