@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 H_LR, W_LR, SCALE = 340, 510, 4
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def synth_lr(seed, h, w):
@@ -127,6 +128,9 @@ def main():
     value = world * args.steps * mp_per_image / dt
 
     # ---- roofline of the dominant kernel: one extra instrumented step on the same stream
+    # (experts run one after the other here: with the four expert streams overlapping, an event pair around one
+    #  launch would also time its neighbours)
+    concurrent, eng.concurrent_experts = eng.concurrent_experts, False
     ops.CONV_PROFILE = []
     eng.process(lrs[0])
     torch.cuda.synchronize(device)
@@ -137,7 +141,8 @@ def main():
     t1 = time.perf_counter()
     eng.process(lrs[0])
     torch.cuda.synchronize(device)
-    step_s = time.perf_counter() - t1
+    step_s = time.perf_counter() - t1          # sequential-experts step, the denominator of kernel_share_of_step
+    eng.concurrent_experts = concurrent
     achieved = flops / conv_s / 1e12
     # per-expert split of one step (diagnostic, stderr only)
     if rank == 0:
@@ -156,8 +161,13 @@ def main():
             log(f"  {name:7s} {1e3 * (time.perf_counter() - t2):8.1f} ms")
         log(f"  conv/GEMM kernel: {len(prof)} launches, {flops / 1e12:.2f} TFLOP, {conv_s * 1e3:.1f} ms -> {achieved:.1f} TFLOP/s; "
             f"whole step {step_s * 1e3:.1f} ms")
-    roofline = {"kernel": "conv_gemm_kernel (f32 MFMA implicit GEMM)", "bound": "mfma", "achieved": achieved,
-                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+    if ops.GEMM_MODE == "bf16x3":
+        kname = "conv_gemm_bf16x3_kernel (implicit GEMM, fp32 operands split into 3 bf16 MFMA products, fp32 accumulate)"
+        peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
+    else:
+        kname, peak = "conv_gemm_kernel (f32-input MFMA implicit GEMM)", MFMA_F32_PEAK_TFLOPS
+    roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                 "launches_per_step": len(prof), "flops_per_launch": flops / len(prof),
                 "mean_launch_us": 1e3 * sum(dur_ms) / len(prof), "kernel_share_of_step": conv_s / step_s}
 
@@ -165,12 +175,12 @@ def main():
         line = {"metric": "SR output megapixels/s (x4, 510x340 LR -> 2040x1360, full 4-expert + 7-phase fusion)",
                 "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic (seeded LR images; random-init weights of the exact architecture)",
+                "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (GEMM/conv products as 3-term split-bf16 MFMA, fp32 accumulate)", "data": "synthetic (seeded LR images; random-init weights of the exact architecture)",
                 "config": {"workload": f"CompleteEnhancedFusionSR hot path: {w}x{h} LR image per step per GPU "
                                        f"(pad16 -> DRCT-L + GRL-B + NAFNet-w64 + MambaIR -> fusion), batch 1",
                            "lr_hw": [h, w], "images_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}",
                            "small_experts": bool(args.small)},
-                "roofline": roofline}
+                "gemm_mode": ops.GEMM_MODE, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             naf_cfg = dict(enc_blks=(1, 1, 1, 1), mid_blks=1, dec_blks=(1, 1, 1, 1)) if args.small else None
             log("cpu_baseline: oracle on one 64x64 tile ...")

@@ -159,11 +159,22 @@ __global__ void scan_carry_kernel(float* __restrict__ hstate, const float* __res
   if (idx >= groups * per) return;
   int g = idx / per, i = idx - g * per;
   float hin = 0.f;
-  for (int c = 0; c < nchunk; ++c) {
-    size_t o = ((size_t)g * nchunk + c) * per + i;
-    float hl = hstate[o], dc = decay[o];
-    hstate[o] = hin;
-    hin = fmaf(dc, hin, hl);
+  constexpr int U = 8;  // loads of U chunks are issued together (they do not depend on the recurrence)
+  for (int c0 = 0; c0 < nchunk; c0 += U) {
+    float hl[U], dc[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const size_t o = ((size_t)g * nchunk + min(c0 + j, nchunk - 1)) * per + i;
+      hl[j] = hstate[o];
+      dc[j] = decay[o];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (c0 + j < nchunk) {
+        hstate[((size_t)g * nchunk + c0 + j) * per + i] = hin;
+        hin = fmaf(dc[j], hin, hl[j]);
+      }
+    }
   }
 }
 

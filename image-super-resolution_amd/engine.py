@@ -7,6 +7,7 @@ results: no per-image mask/table rebuilds or H2D copies (SURVEY.md section 3.1 (
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import numpy as np
@@ -37,27 +38,47 @@ class Engine:
             self.nafnet = NAFNetSR(weights["nafnet"], self.device, scale)
             self.mamba = MambaIR(weights["mamba"], self.device)
             self.fusion = FusionNet(weights["fusion"], self.device, scale)
+            self.concurrent_experts = os.environ.get("FFSR_CONCURRENT_EXPERTS", "1") != "0"
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(4)]
 
     # -------------------------------------------------------------------------------------- experts
     def run_experts(self, lr):
-        """lr [B,h,w,3] float map -> (imgs, feats) as io._process_image builds them (io.py:224-278)."""
+        """lr [B,h,w,3] float map -> (imgs, feats) as io._process_image builds them (io.py:224-278).
+        The four experts are independent: each runs on its own HIP stream so their launch tails and small kernels
+        overlap; the caller's stream waits for all four before the fusion starts."""
         B, h, w, _ = lr.shape
         s = self.scale
         hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
         lp = ops.pad_reflect(lr, hp, wp)
         imgs, feats = {}, {}
-        for name, model in (("drct", self.drct), ("grl", self.grl)):
+
+        def swin_like(name, model):
             sr, f = model(lp)
             imgs[name] = ops.crop(sr, h * s, w * s, clamp=True)
             feats[name] = ops.crop(f, h, w)
-            del sr, f
-        sr, f = self.nafnet(lp)
-        imgs["nafnet"] = ops.crop(sr, h * s, w * s)
-        feats["nafnet"] = ops.bilinear(f, h, w)          # padded HR map straight to (h, w): io.py:256-258
-        del sr, f
-        sr, f = self.mamba(lp)
-        imgs["mamba"] = ops.crop(sr, h * s, w * s, clamp=True)
-        feats["mamba"] = ops.crop(f, h, w)
+
+        def naf():
+            sr, f = self.nafnet(lp)
+            imgs["nafnet"] = ops.crop(sr, h * s, w * s)
+            feats["nafnet"] = ops.bilinear(f, h, w)          # padded HR map straight to (h, w): io.py:256-258
+
+        jobs = [lambda: swin_like("drct", self.drct), lambda: swin_like("mamba", self.mamba),
+                lambda: swin_like("grl", self.grl), naf]
+        if not self.concurrent_experts:
+            for job in jobs:
+                job()
+            return imgs, feats
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for job, stream in zip(jobs, self._streams):
+            stream.wait_event(ready)
+            with torch.cuda.stream(stream):
+                job()
+        for stream in self._streams:
+            main.wait_stream(stream)
+        for t in list(imgs.values()) + list(feats.values()) + [lp]:
+            t.record_stream(main)
         return imgs, feats
 
     def process(self, lr):
