@@ -414,6 +414,226 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   return ffsr_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x3, second generation (the default data path).  Differences to conv_gemm_bf16x3_kernel above:
+//  * weights arrive PRE-SPLIT (bf16 hi / lo planes [Npad, Kpad], zero padded to multiples of BN / 32 at pack time):
+//    the B tile is 16-byte loads straight into LDS rows, no checks, no VALU;
+//  * out-of-image taps / rows read a caller-provided zero page instead of being masked: no multiplies, no NaN hazard;
+//  * A addressing is hoisted: per row one base offset + a bitmask of valid taps; per K step one table lookup
+//    (tap -> pixel offset, in LDS) -- the 1x1 (token GEMM) case degenerates to base + k;
+//  * BN is 64 or 128 (one A pass serves twice the columns).
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvArgs3 {
+  const float* in;
+  const unsigned short* whi;
+  const unsigned short* wlo;
+  const float* zeros;  // >= 64 bytes of zeros
+  const float* bias;
+  float* out;
+  const float* res;
+  const float* cvec;
+  const float* rvec;
+  const float* akscale;
+  int B, H, W, Cin, ldi;
+  int N, Ho, Wo, ldo, ldr, ldw;  // ldw = padded K (elements) of the weight planes
+  int KH, KW, stride, pad_h, pad_w;
+  int act;
+  float slope, cscale, rscale;
+  int shuffle;
+  int M, Ktot, akrows;
+};
+
+template <int BN, bool HAS_AK>
+__global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
+  constexpr int BM = 128, WM = 64, WN = BN / 2;
+  constexpr int TM = 2, TN = WN / 32;
+  constexpr int AR = BM / 32, BRW = BN / 64;
+  constexpr int RS = 80;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * RS];
+  __shared__ int tapoff[32];
+  unsigned char* const Ahi = smem;
+  unsigned char* const Alo = Ahi + BM * RS;
+  unsigned char* const Bhi = Alo + BM * RS;
+  unsigned char* const Blo = Bhi + BN * RS;
+
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+  const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kofs = (tid & 7) * 4;
+  const int rbase = tid >> 3;
+  const int ntap = p.KH * p.KW;
+  if (tid < ntap) tapoff[tid] = ((tid / p.KW) * p.W + (tid % p.KW)) * p.ldi;
+
+  // ---- per-row base offset (element index of tap (0,0)) and bitmask of in-image taps
+  long long a_base[AR];
+  unsigned a_mask[AR];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + rbase + 32 * i;
+    a_base[i] = 0;
+    a_mask[i] = 0;
+    if (m < p.M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+      a_base[i] = ((long long)(b * p.H + iy0) * p.W + ix0) * p.ldi;
+      unsigned mk = 0;
+      for (int t = 0; t < ntap; ++t) {
+        const int yy = iy0 + t / p.KW, xx = ix0 + t % p.KW;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
+    }
+  }
+  __syncthreads();  // tapoff visible
+
+  // (a two-K-step-ahead register prefetch was tried: +24 VGPRs drop the kernel from 4 to 2 waves per SIMD and it
+  //  runs 25-30 % slower -- occupancy hides the load latency better than a deeper per-wave prefetch does)
+  floatx4 a_reg[AR];
+  floatx4 bh_reg[BRW], bl_reg[BRW];   // 8 bf16 each
+  const int brow = tid >> 2, bseg = (tid & 3) * 8;  // B loader: row, first k of its 8-element segment
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + kofs;
+    int tap = 0, ci = k;
+    if (ntap > 1) {
+      tap = k / p.Cin;
+      ci = k - tap * p.Cin;
+    }
+    const bool kval = k < p.Ktot;
+    const int toff = tapoff[kval ? tap : 0] + ci;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const bool ok = kval && ((a_mask[i] >> tap) & 1u);
+      const float* src = ok ? p.in + (a_base[i] + toff) : p.zeros;
+      a_reg[i] = *reinterpret_cast<const floatx4*>(src);
+    }
+    if (HAS_AK) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int m = min(m0 + rbase + 32 * i, p.M - 1);
+        const size_t off = (size_t)(m / p.akrows) * p.Ktot + (kval ? k : 0);
+        a_reg[i] *= *reinterpret_cast<const floatx4*>(p.akscale + off);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BRW; ++j) {
+      const size_t off = (size_t)(n0 + brow + 64 * j) * p.ldw + kt * BK + bseg;   // planes are padded: always valid
+      bh_reg[j] = *reinterpret_cast<const floatx4*>(p.whi + off);
+      bl_reg[j] = *reinterpret_cast<const floatx4*>(p.wlo + off);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      uintx2 hi, lo;
+      split4(a_reg[i], hi, lo);
+      const int o = (rbase + 32 * i) * RS + kofs * 2;
+      *reinterpret_cast<uintx2*>(Ahi + o) = hi;
+      *reinterpret_cast<uintx2*>(Alo + o) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < BRW; ++j) {
+      const int o = (brow + 64 * j) * RS + bseg * 2;
+      *reinterpret_cast<floatx4*>(Bhi + o) = bh_reg[j];
+      *reinterpret_cast<floatx4*>(Blo + o) = bl_reg[j];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wrow = (wave >> 1) * WM, wcol = (wave & 1) * WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (p.Ktot + BK - 1) / BK;
+
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ko = 32 * ks + 16 * h;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + (wrow + i * 32 + r) * RS + ko);
+        al[i] = *reinterpret_cast<const bf16x8*>(Alo + (wrow + i * 32 + r) * RS + ko);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + (wcol + j * 32 + r) * RS + ko);
+        bl[j] = *reinterpret_cast<const bf16x8*>(Blo + (wcol + j * 32 + r) * RS + ko);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) store_tiles();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + wcol + jn * 32 + r;
+    if (n >= p.N) continue;
+    const float bia = p.bias ? p.bias[n] : 0.f;
+    const float cs = (p.cvec ? p.cvec[n] : 1.f) * p.cscale;
+    const float rs = (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wrow + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = ffsr_act(acc[im][jn][e] + bia, p.act, p.slope) * cs;
+        size_t opix;
+        int oc = n;
+        if (p.shuffle) {
+          int b = m / HoWo, rem = m - b * HoWo;
+          int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          oc = n >> 2;
+          opix = ((size_t)b * 2 * p.Ho + 2 * oy + ((n >> 1) & 1)) * (2 * p.Wo) + 2 * ox + (n & 1);
+        } else {
+          opix = (size_t)m;
+        }
+        if (p.res) v += p.res[opix * p.ldr + oc] * rs;
+        p.out[opix * p.ldo + oc] = v;
+      }
+    }
+  }
+}
+
+template <int BN>
+int launch_v3(const ConvArgs3& a, hipStream_t st) {
+  int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
+  if (a.akscale)
+    hipLaunchKernelGGL((conv_gemm_bf16x3_v3_kernel<BN, true>), dim3(tiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_gemm_bf16x3_v3_kernel<BN, false>), dim3(tiles), dim3(256), 0, st, a);
+  return ffsr_launch_status();
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 int launch(const ConvArgs& a, hipStream_t st) {
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
@@ -473,4 +693,36 @@ extern "C" int ffsr_conv2d_f32(const float* in, const float* wgt, const float* b
     case 21: return launch_bf16x3<256, 32, 4, 1>(a, st);
     default: return FFSR_EINVAL;
   }
+}
+
+// Split-bf16 convolution with pre-split weights: see include/ffsr.h.
+extern "C" int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, int ldw, int n_rows_padded,
+                                  const float* zeros, const float* bias, float* out, const float* res, const float* cvec,
+                                  const float* rvec, const float* akscale, int B, int H, int W, int Cin, int ldi, int N,
+                                  int ldo, int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                                  float cscale, float rscale, int shuffle, int akrows, int bn, void* stream) {
+  FFSR_CHECK(in && wgt_hi && wgt_lo && zeros && out);
+  FFSR_CHECK(B > 0 && H > 0 && W > 0 && N > 0 && KH > 0 && KW > 0 && KH * KW <= 32 && stride > 0);
+  FFSR_CHECK(Cin > 0 && (Cin & 3) == 0 && (ldi & 3) == 0 && ldi >= Cin);
+  FFSR_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)wgt_hi & 15) == 0 && ((uintptr_t)wgt_lo & 15) == 0 &&
+             ((uintptr_t)zeros & 15) == 0);
+  FFSR_CHECK(shuffle == 0 || (shuffle == 2 && (N & 3) == 0));
+  FFSR_CHECK(!akscale || (KH * KW == 1 && akrows > 0 && ((uintptr_t)akscale & 15) == 0));
+  FFSR_CHECK(bn == 64 || bn == 128);
+  const int Ktot = KH * KW * Cin;
+  FFSR_CHECK((ldw & 31) == 0 && ldw >= Ktot && (n_rows_padded % bn) == 0 && n_rows_padded >= N);
+  ConvArgs3 a;
+  a.in = in; a.whi = (const unsigned short*)wgt_hi; a.wlo = (const unsigned short*)wgt_lo; a.zeros = zeros; a.bias = bias;
+  a.out = out; a.res = res; a.cvec = cvec; a.rvec = rvec; a.akscale = akscale;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldi = ldi; a.N = N;
+  a.Ho = (H + 2 * pad_h - KH) / stride + 1;
+  a.Wo = (W + 2 * pad_w - KW) / stride + 1;
+  FFSR_CHECK(a.Ho > 0 && a.Wo > 0);
+  a.ldo = ldo; a.ldr = ldr; a.ldw = ldw; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.act = act; a.slope = slope; a.cscale = cscale; a.rscale = rscale; a.shuffle = shuffle;
+  a.Ktot = Ktot; a.akrows = akrows > 0 ? akrows : 1;
+  long long M = (long long)B * a.Ho * a.Wo;
+  FFSR_CHECK(M < (1ll << 31) && (long long)B * H * W < (1ll << 31));
+  a.M = (int)M;
+  return bn == 64 ? launch_v3<64>(a, (hipStream_t)stream) : launch_v3<128>(a, (hipStream_t)stream);
 }

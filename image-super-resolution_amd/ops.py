@@ -27,6 +27,9 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SILU = range(6)
 GEMM_MODE = os.environ.get("FFSR_GEMM_MODE", "bf16x3")
 
 
+BN128_MIN_N = 1 << 30   # the 128-column tile (2 waves/SIMD) measured slower on every shape: keep BN = 64
+
+
 def set_gemm_mode(mode: str):
     global GEMM_MODE
     assert mode in ("f32", "bf16x3")
@@ -106,6 +109,8 @@ class Conv:
     stride: int = 1
     pad: int = 0
     Cin_true: int = 0   # unpadded input channels (algorithmic flop accounting)
+    whi: Optional[torch.Tensor] = None   # bf16 hi plane [Npad, Kpad] (split-bf16 path)
+    wlo: Optional[torch.Tensor] = None   # bf16 lo plane
 
 
 def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
@@ -121,8 +126,26 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=
     wp[..., :Cin] = w.permute(0, 2, 3, 1)
     if pad is None:
         pad = KH // 2
-    return Conv(wp.reshape(N, KH * KW * Cp).contiguous().to(device),
-                None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride, pad, Cin)
+    w2 = wp.reshape(N, KH * KW * Cp).contiguous()
+    # pre-split planes for the bf16x3 kernel: hi = bf16(w), lo = bf16(w - hi); rows padded to x128, K to x32
+    Np, Kp = (N + 127) // 128 * 128, (KH * KW * Cp + 31) // 32 * 32
+    hi = torch.zeros(Np, Kp, dtype=torch.bfloat16)
+    lo = torch.zeros(Np, Kp, dtype=torch.bfloat16)
+    h = w2.to(torch.bfloat16)
+    hi[:N, :w2.shape[1]] = h
+    lo[:N, :w2.shape[1]] = (w2 - h.float()).to(torch.bfloat16)
+    return Conv(w2.to(device), None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride,
+                pad, Cin, hi.to(device), lo.to(device))
+
+
+_ZEROS = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(64, device=device)
+    return _ZEROS[key]
 
 
 def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
@@ -149,15 +172,21 @@ def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[
     if akscale is not None:
         assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
         akrows = H * W
-    if tile_hint == 0 and GEMM_MODE == "bf16x3" and B * Ho * Wo > 64 * 24:
-        tile_hint = 21 if cv.N <= 32 else 20
+    if tile_hint == 0 and GEMM_MODE == "bf16x3" and B * Ho * Wo > 64 * 24 and cv.KH * cv.KW <= 32:
+        tile_hint = 64 if cv.N <= 64 or BN128_MIN_N > cv.N else 128
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    hip.call("ffsr_conv2d_f32", _ptr(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
-             _ptr(akscale), B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad,
-             act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+    if tile_hint in (64, 128):
+        hip.call("ffsr_conv2d_bf16x3", _ptr(x), _ptr(cv.whi), _ptr(cv.wlo), cv.whi.shape[1], cv.whi.shape[0],
+                 _ptr(zero_page(x.device)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec), _ptr(akscale),
+                 B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope),
+                 float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+    else:
+        hip.call("ffsr_conv2d_f32", _ptr(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
+                 _ptr(akscale), B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad,
+                 act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true,
