@@ -135,8 +135,9 @@ def main():
     eng.process(lrs[0])
     torch.cuda.synchronize(device)
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    dur_ms = [a.elapsed_time(b) for a, b, _, _ in prof]
-    flops = sum(f for _, _, f, _ in prof)
+    dur_ms = [a.elapsed_time(b) for a, b, *_ in prof]
+    flops = sum(t[2] for t in prof)
+    algo_bytes = sum(t[4] for t in prof)
     conv_s = sum(dur_ms) / 1e3
     t1 = time.perf_counter()
     eng.process(lrs[0])
@@ -147,7 +148,7 @@ def main():
     # per-expert split of one step (diagnostic, stderr only)
     if rank == 0:
         by_shape = {}
-        for (e0, e1, f, shape), ms in zip(prof, dur_ms):
+        for (e0, e1, f, shape, _), ms in zip(prof, dur_ms):
             t = by_shape.setdefault(shape, [0, 0.0, 0.0])
             t[0] += 1; t[1] += ms; t[2] += f
         for shape, (n, ms, f) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:14]:
@@ -166,8 +167,16 @@ def main():
         peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
     else:
         kname, peak = "conv_gemm_kernel (f32-input MFMA implicit GEMM)", MFMA_F32_PEAK_TFLOPS
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv_gemm.json")
+    if ops.GEMM_MODE == "bf16x3" and (h, w) == (H_LR, W_LR) and os.path.exists(tfile):
+        # PMC counters cannot be read from inside this process: the per-launch HBM bytes come from the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (corrected as the guide prescribes)
+        traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
+        traffic_src = "profiles/r01_pmc_traffic_conv_gemm.json"
     roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": algo_bytes / len(prof),
                 "launches_per_step": len(prof), "flops_per_launch": flops / len(prof),
                 "mean_launch_us": 1e3 * sum(dur_ms) / len(prof), "kernel_share_of_step": conv_s / step_s}
 

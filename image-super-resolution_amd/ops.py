@@ -190,7 +190,9 @@ def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true,
-                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH)))
+                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH),
+                     4.0 * (B * H * W * cv.Cin_true + cv.N * cv.KH * cv.KW * cv.Cin_true
+                            + B * Ho * Wo * cv.N * (2 if res is not None else 1))))
     return out
 
 
