@@ -37,12 +37,13 @@ def _imread_uint(path):
     """uint8 HxWx3 RGB (cv2.imread + BGR->RGB of the reference, via PIL; grey is expanded, alpha dropped)."""
     from PIL import Image
     with Image.open(path) as im:
-        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+        return np.array(im.convert("RGB"), dtype=np.uint8)
 
 
 def _imsave(img, path):
     from PIL import Image
-    Image.fromarray(img).save(path)
+    kw = {"compress_level": 1} if path.lower().endswith(".png") else {}     # cv2.imwrite's default PNG level
+    Image.fromarray(img).save(path, **kw)
 
 
 def _load_engine(model_dir, device):
@@ -78,10 +79,20 @@ def main(model_dir, input_path, output_path, device=None):
     os.makedirs(output_path, exist_ok=True)
     mine = _pkg("shard").shard(input_imgs, rank, world)
     print(f"  Processing {len(mine)} of {len(input_imgs)} images on rank {rank}/{world} ...")
-    for img_path in mine:
-        name, ext = os.path.splitext(os.path.basename(img_path))
-        sr = eng.process_u8(_imread_uint(img_path))
-        _imsave(sr, os.path.join(output_path, name + ext))
+    # host pipeline: the next image is decoded and the previous results are encoded on worker threads while the GPU
+    # works on the current one; everything is joined before returning (test.py times the whole call, test.py:63-70)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("FFSR_IO_THREADS", "4"))) as pool:
+        saves = []
+        nxt = pool.submit(_imread_uint, mine[0]) if mine else None
+        for i, img_path in enumerate(mine):
+            img = nxt.result()
+            nxt = pool.submit(_imread_uint, mine[i + 1]) if i + 1 < len(mine) else None
+            name, ext = os.path.splitext(os.path.basename(img_path))
+            sr = eng.process_u8(img)
+            saves.append(pool.submit(_imsave, sr, os.path.join(output_path, name + ext)))
+        for f in saves:
+            f.result()
     torch.cuda.synchronize(device)
     if world > 1:
         torch.distributed.barrier()
