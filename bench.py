@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 H_LR, W_LR, SCALE = 340, 510, 4
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s measured achievable)
 
 
 def synth_lr(seed, h, w):
@@ -163,10 +164,10 @@ def main():
         log(f"  conv/GEMM kernel: {len(prof)} launches, {flops / 1e12:.2f} TFLOP, {conv_s * 1e3:.1f} ms -> {achieved:.1f} TFLOP/s; "
             f"whole step {step_s * 1e3:.1f} ms")
     if ops.GEMM_MODE == "bf16x3":
-        kname = "conv_gemm_bf16x3_kernel (implicit GEMM, fp32 operands split into 3 bf16 MFMA products, fp32 accumulate)"
-        peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
+        kname = "conv_gemm_bf16x3_v3_kernel (implicit GEMM; fp32 operands as 3-term split-bf16 MFMA products, fp32 accumulate)"
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
     else:
-        kname, peak = "conv_gemm_kernel (f32-input MFMA implicit GEMM)", MFMA_F32_PEAK_TFLOPS
+        kname, mfma_peak = "conv_gemm_kernel (f32-input MFMA implicit GEMM)", MFMA_F32_PEAK_TFLOPS
     traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv_gemm.json")
     if ops.GEMM_MODE == "bf16x3" and (h, w) == (H_LR, W_LR) and os.path.exists(tfile):
@@ -174,11 +175,23 @@ def main():
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (corrected as the guide prescribes)
         traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
         traffic_src = "profiles/r01_pmc_traffic_conv_gemm.json"
-    roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": algo_bytes / len(prof),
-                "launches_per_step": len(prof), "flops_per_launch": flops / len(prof),
-                "mean_launch_us": 1e3 * sum(dur_ms) / len(prof), "kernel_share_of_step": conv_s / step_s}
+    n_l = len(prof)
+    mean_s = conv_s / n_l
+    bytes_l, flops_l = algo_bytes / n_l, flops / n_l
+    gbps = bytes_l / mean_s / 1e9
+    # the binding roofline of the average launch = the larger of its two lower bounds
+    t_mfma, t_hbm = flops_l / (mfma_peak * 1e12), bytes_l / (HBM_PEAK_GBPS * 1e9)
+    if t_hbm >= t_mfma:
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBPS}
+    else:
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
+                    "frac": achieved / mfma_peak}
+    roofline.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_l,
+                     "algorithmic_flops_per_launch": flops_l, "launches_per_step": n_l, "mean_launch_us": mean_s * 1e6,
+                     "mfma_view": {"achieved_tflops": achieved, "peak_tflops": mfma_peak, "frac": achieved / mfma_peak},
+                     "hbm_view": {"achieved_gbps": gbps, "peak_gbps": HBM_PEAK_GBPS, "frac": gbps / HBM_PEAK_GBPS},
+                     "kernel_share_of_step": conv_s / step_s})
 
     if rank == 0:
         line = {"metric": "SR output megapixels/s (x4, 510x340 LR -> 2040x1360, full 4-expert + 7-phase fusion)",

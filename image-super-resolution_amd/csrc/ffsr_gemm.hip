@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 // Split-bf16 ("bf16x3") variant: every fp32 operand is split on the fly into hi = bf16(x), lo = bf16(x - hi) and the
 // product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped lo*lo
 // term and the split residue bound the per-product relative error by ~3 * 2^-18 (1.1e-5) -- 3 MFMAs at 16x the f32
-// MFMA rate.  Same tiling, loaders and epilogue as the exact kernel; LDS holds bf16 hi/lo planes with 80-byte rows
-// (5 x 16 B: odd -> ds_read_b128 conflict-free).  Opt-in (tile_hint 20/21); the exact f32 kernel stays the default.
+// MFMA rate.  Same tiling and epilogue as the exact kernel; LDS holds bf16 hi/lo planes with 80-byte rows
+// (5 x 16 B: odd -> ds_read_b128 conflict-free).  Entry point: ffsr_conv2d_bf16x3 (the engine's default GEMM mode).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -228,195 +228,8 @@ __device__ __forceinline__ void split4(const floatx4 v, uintx2& hi, uintx2& lo) 
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_AK>
-__global__ __launch_bounds__(256) void conv_gemm_bf16x3_kernel(ConvArgs p) {
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int AR = BM / 32, BR = BN / 32;
-  constexpr int RS = 80;  // LDS row stride in bytes (32 bf16 + 16 B pad)
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * RS];
-  unsigned char* const Ahi = smem;
-  unsigned char* const Alo = Ahi + BM * RS;
-  unsigned char* const Bhi = Alo + BM * RS;
-  unsigned char* const Blo = Bhi + BN * RS;
-
-  const int nwg = gridDim.x;
-  const int orig = blockIdx.x;
-  const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
-  const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int m0 = (tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int kofs = (tid & 7) * 4;
-  const int rbase = tid >> 3;
-
-  int a_iy0[AR], a_ix0[AR], a_pix[AR];
-  const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    int m = m0 + rbase + 32 * i;
-    if (m < p.M) {
-      int b = m / HoWo, rem = m - b * HoWo;
-      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[i] = oy * p.stride - p.pad_h;
-      a_ix0[i] = ox * p.stride - p.pad_w;
-      a_pix[i] = b * p.H * p.W;
-    } else {
-      a_iy0[i] = -(1 << 28);
-      a_ix0[i] = 0;
-      a_pix[i] = 0;
-    }
-  }
-  floatx4 a_reg[AR], b_reg[BR];
-  float a_ok[AR], b_ok[BR];
-  const bool is1x1 = (p.KH * p.KW == 1);
-  auto load_tiles = [&](int kt) {
-    const int k = kt * BK + kofs;
-    const bool kval = k < p.Ktot;
-    int ky = 0, kx = 0, ci = k;
-    if (!is1x1) {
-      int tap = k / p.Cin;
-      ci = k - tap * p.Cin;
-      ky = tap / p.KW;
-      kx = tap - ky * p.KW;
-    }
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int yy = a_iy0[i] + ky, xx = a_ix0[i] + kx;
-      const bool ok = kval && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      a_ok[i] = ok ? 1.f : 0.f;
-      const size_t off = ok ? (size_t)(a_pix[i] + yy * p.W + xx) * p.ldi + ci : 0;
-      a_reg[i] = *reinterpret_cast<const floatx4*>(p.in + off);
-    }
-    if (HAS_AK) {
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const int m = min(m0 + rbase + 32 * i, p.M - 1);
-        const size_t off = (size_t)(m / p.akrows) * p.Ktot + (kval ? k : 0);
-        a_reg[i] *= *reinterpret_cast<const floatx4*>(p.akscale + off);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int n = n0 + rbase + 32 * i;
-      const bool ok = kval && n < p.N;
-      b_ok[i] = ok ? 1.f : 0.f;
-      const size_t off = ok ? (size_t)n * p.ldw + k : 0;
-      b_reg[i] = *reinterpret_cast<const floatx4*>(p.wgt + off);
-    }
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      uintx2 hi, lo;
-      split4(a_reg[i] * a_ok[i], hi, lo);
-      const int o = (rbase + 32 * i) * RS + kofs * 2;
-      *reinterpret_cast<uintx2*>(Ahi + o) = hi;
-      *reinterpret_cast<uintx2*>(Alo + o) = lo;
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      uintx2 hi, lo;
-      split4(b_reg[i] * b_ok[i], hi, lo);
-      const int o = (rbase + 32 * i) * RS + kofs * 2;
-      *reinterpret_cast<uintx2*>(Bhi + o) = hi;
-      *reinterpret_cast<uintx2*>(Blo + o) = lo;
-    }
-  };
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int wrow = (wave / WAVES_N) * WM, wcol = (wave % WAVES_N) * WN;
-  const int r = lane & 31, h = lane >> 5;
-  const int nk = (p.Ktot + BK - 1) / BK;
-
-  load_tiles(0);
-  store_tiles();
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {   // two 16-wide MFMA k-steps; lane half h holds k = 16 ks + 8 h .. + 7
-      const int ko = 32 * ks + 16 * h;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + (wrow + i * 32 + r) * RS + ko);
-        al[i] = *reinterpret_cast<const bf16x8*>(Alo + (wrow + i * 32 + r) * RS + ko);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + (wcol + j * 32 + r) * RS + ko);
-        bl[j] = *reinterpret_cast<const bf16x8*>(Blo + (wcol + j * 32 + r) * RS + ko);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    if (kt + 1 < nk) store_tiles();
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int jn = 0; jn < TN; ++jn) {
-    const int n = n0 + wcol + jn * 32 + r;
-    if (n >= p.N) continue;
-    const float bia = p.bias ? p.bias[n] : 0.f;
-    const float cs = (p.cvec ? p.cvec[n] : 1.f) * p.cscale;
-    const float rs = (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wrow + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = ffsr_act(acc[im][jn][e] + bia, p.act, p.slope) * cs;
-        size_t opix;
-        int oc = n;
-        if (p.shuffle) {
-          int b = m / HoWo, rem = m - b * HoWo;
-          int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          oc = n >> 2;
-          opix = ((size_t)b * 2 * p.Ho + 2 * oy + ((n >> 1) & 1)) * (2 * p.Wo) + 2 * ox + (n & 1);
-        } else {
-          opix = (size_t)m;
-        }
-        if (p.res) v += p.res[opix * p.ldr + oc] * rs;
-        p.out[opix * p.ldo + oc] = v;
-      }
-    }
-  }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
-  int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  if (a.akscale)
-    hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(tiles), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3(tiles), dim3(256), 0, st, a);
-  return ffsr_launch_status();
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// bf16x3, second generation (the default data path).  Differences to conv_gemm_bf16x3_kernel above:
+// The kernel (the default data path).  Compared with the exact kernel's loader:
 //  * weights arrive PRE-SPLIT (bf16 hi / lo planes [Npad, Kpad], zero padded to multiples of BN / 32 at pack time):
 //    the B tile is 16-byte loads straight into LDS rows, no checks, no VALU;
 //  * out-of-image taps / rows read a caller-provided zero page instead of being masked: no multiplies, no NaN hazard;
@@ -476,28 +289,36 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
   long long a_base[AR];
   unsigned a_mask[AR];
   const int HoWo = p.Ho * p.Wo;
+  const bool plain = ntap == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0;   // token GEMM: row m of A is pixel m
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = m0 + rbase + 32 * i;
     a_base[i] = 0;
     a_mask[i] = 0;
     if (m < p.M) {
-      const int b = m / HoWo, rem = m - b * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
-      a_base[i] = ((long long)(b * p.H + iy0) * p.W + ix0) * p.ldi;
-      unsigned mk = 0;
-      for (int t = 0; t < ntap; ++t) {
-        const int yy = iy0 + t / p.KW, xx = ix0 + t % p.KW;
-        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+      if (plain) {
+        a_base[i] = (long long)m * p.ldi;
+        a_mask[i] = 1u;
+      } else {
+        const int b = m / HoWo, rem = m - b * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+        a_base[i] = ((long long)(b * p.H + iy0) * p.W + ix0) * p.ldi;
+        unsigned mk = 0;
+        for (int t = 0; t < ntap; ++t) {
+          const int yy = iy0 + t / p.KW, xx = ix0 + t % p.KW;
+          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
       }
-      a_mask[i] = mk;
     }
   }
   __syncthreads();  // tapoff visible
 
-  // (a two-K-step-ahead register prefetch was tried: +24 VGPRs drop the kernel from 4 to 2 waves per SIMD and it
-  //  runs 25-30 % slower -- occupancy hides the load latency better than a deeper per-wave prefetch does)
+  // Tried and rejected on MI355X (tools/gemm_bench.py): a two-K-step-ahead register prefetch (+24 VGPRs -> 2 instead
+  // of 4 waves per SIMD: 25-30 % slower -- occupancy hides the load latency better than a deeper per-wave prefetch);
+  // BN = 128 (2 waves per SIMD: slower on every shape); an A-stationary "row strip" kernel reading the weight
+  // fragments straight from L2 (fragment-shaped 32-byte loads saturate the texture-address path: 20-50 % slower).
   floatx4 a_reg[AR];
   floatx4 bh_reg[BRW], bl_reg[BRW];   // 8 bf16 each
   const int brow = tid >> 2, bseg = (tid & 3) * 8;  // B loader: row, first k of its 8-element segment
@@ -593,6 +414,9 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
     __syncthreads();
   }
 
+  // ---- epilogue.  Lean path (no PixelShuffle): one pointer per lane, compile-time row offsets, the activation switch
+  // hoisted out of the element loop; rows are bounds-checked only in the last row tile.
+  const bool full_rows = m0 + BM <= p.M;
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
     const int n = n0 + wcol + jn * 32 + r;
@@ -602,23 +426,45 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
     const float rs = (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
+      floatx16 v = acc[im][jn];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wrow + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = ffsr_act(acc[im][jn][e] + bia, p.act, p.slope) * cs;
-        size_t opix;
-        int oc = n;
-        if (p.shuffle) {
-          int b = m / HoWo, rem = m - b * HoWo;
-          int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          oc = n >> 2;
-          opix = ((size_t)b * 2 * p.Ho + 2 * oy + ((n >> 1) & 1)) * (2 * p.Wo) + 2 * ox + (n & 1);
-        } else {
-          opix = (size_t)m;
+      for (int e = 0; e < 16; ++e) v[e] += bia;
+      switch (p.act) {   // wave-uniform
+        case FFSR_ACT_NONE: break;
+        case FFSR_ACT_GELU:
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+          break;
+        default:
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = ffsr_act(v[e], p.act, p.slope);
+      }
+      const int mrow = m0 + wrow + im * 32 + 4 * h;   // + (e&3) + 8*(e>>2)
+      if (!p.shuffle) {
+        float* op = p.out + (size_t)mrow * p.ldo + n;
+        const float* rp = p.res ? p.res + (size_t)mrow * p.ldr + n : nullptr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          if (full_rows || mrow + dr < p.M) {
+            float o = v[e] * cs;
+            if (rp) o += rp[dr * p.ldr] * rs;
+            op[dr * p.ldo] = o;
+          }
         }
-        if (p.res) v += p.res[opix * p.ldr + oc] * rs;
-        p.out[opix * p.ldo + oc] = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mrow + (e & 3) + 8 * (e >> 2);
+          if (m >= p.M) continue;
+          const int b = m / HoWo, rem = m - b * HoWo;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const int oc = n >> 2;
+          const size_t opix = ((size_t)b * 2 * p.Ho + 2 * oy + ((n >> 1) & 1)) * (2 * p.Wo) + 2 * ox + (n & 1);
+          float o = v[e] * cs;
+          if (p.res) o += p.res[opix * p.ldr + oc] * rs;
+          p.out[opix * p.ldo + oc] = o;
+        }
       }
     }
   }
@@ -689,8 +535,6 @@ extern "C" int ffsr_conv2d_f32(const float* in, const float* wgt, const float* b
     case 11: return launch<128, 128, 2, 2, 1>(a, st);   // single LDS stage: more workgroups per CU
     case 12: return launch<128, 64, 2, 2, 1>(a, st);
     case 13: return launch<256, 32, 4, 1, 1>(a, st);
-    case 20: return launch_bf16x3<128, 64, 2, 2>(a, st);   // split-bf16 (3-term) MFMA, opt-in
-    case 21: return launch_bf16x3<256, 32, 4, 1>(a, st);
     default: return FFSR_EINVAL;
   }
 }
@@ -710,7 +554,7 @@ extern "C" int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const voi
   FFSR_CHECK(!akscale || (KH * KW == 1 && akrows > 0 && ((uintptr_t)akscale & 15) == 0));
   FFSR_CHECK(bn == 64 || bn == 128);
   const int Ktot = KH * KW * Cin;
-  FFSR_CHECK((ldw & 31) == 0 && ldw >= Ktot && (n_rows_padded % bn) == 0 && n_rows_padded >= N);
+  FFSR_CHECK((ldw & 31) == 0 && ldw >= Ktot && (n_rows_padded % 128) == 0 && n_rows_padded >= N);
   ConvArgs3 a;
   a.in = in; a.whi = (const unsigned short*)wgt_hi; a.wlo = (const unsigned short*)wgt_lo; a.zeros = zeros; a.bias = bias;
   a.out = out; a.res = res; a.cvec = cvec; a.rvec = rvec; a.akscale = akscale;
