@@ -32,8 +32,8 @@ __device__ __forceinline__ int region_id(int p, int n, int ws, int shift) {
 // registers, so (a) the softmax row statistics are in-lane reductions plus one xor-32 exchange, and (b) the P^T tile
 // is already laid out as the B operand of O^T += V^T P^T -- probabilities never touch LDS.  Q fragments live in
 // registers; K / V tiles are staged through LDS once per workgroup.  biasT: [heads, N keys, N queries].
-template <int DT>  // DT = number of 32-wide head_dim tiles (hd <= 32*DT)
-__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(WinArgs p) {
+template <int DT, int QT>  // DT = 32-wide head_dim tiles (hd <= 32*DT); QT = 32-query tiles per wave (WG = 128*QT queries)
+__global__ __launch_bounds__(256, (QT == 1 ? (DT == 1 ? 4 : (DT == 2 ? 3 : 2)) : (DT <= 2 ? 2 : 1))) void window_attn_kernel(WinArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NGMAX = 4 * DT;       // 8-wide k groups
   const int N = p.ws * p.ws;          // tokens per window (256)
@@ -56,12 +56,15 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
     tok_pix[t] = (b * p.H + y) * p.W + x;
     tok_reg[t] = p.masked ? region_id(ys, p.H, p.ws, p.shift) * 3 + region_id(xs, p.W, p.ws, p.shift) : 0;
   }
+  // only the windows of the last window row / column straddle regions of the shifted image
+  const bool use_mask = p.masked && (wy == nwy - 1 || wx == nwx - 1);
   const int hd = p.hd, hdp = p.hdp, ng = hdp >> 3;
   const int r32 = lane & 31, hh = lane >> 5;
   const float* qbase = p.qkv + head * hd;
+  const int q0 = (QT == 1 ? (int)blockIdx.z * 128 : 0) + wave * 32 * QT;   // first query (window token) of this wave
 
   // ---- Q fragments -> registers (staged through LDS, 128 tokens per round)
-  floatx4 qf[2][NGMAX];
+  floatx4 qf[QT][NGMAX];
   // tile loader: rows wave, wave+4, ... of a 64-row tile; all global loads of a batch are issued before any LDS
   // store (unconditional, clamped column + 0/1 mask: a load under a branch would be waited for one by one)
   constexpr int DI = DT > 2 ? 2 : 1;   // 64-lane column passes per row (hd <= 64 * DI)
@@ -94,31 +97,42 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
       }
     }
   };
-  for (int round = 0; round < 2; ++round) {
+  // stage this workgroup's 128*QT queries through the K/V buffer, 128 at a time
+  for (int round = 0; round < QT; ++round) {
+    const int qb = (QT == 1 ? (int)blockIdx.z * 128 : round * 128);
     __syncthreads();
-    load_rows(round * 128, 0, p.scale, KV);
-    load_rows(round * 128 + 64, 0, p.scale, KV + 64 * QS);
+    load_rows(qb, 0, p.scale, KV);
+    load_rows(qb + 64, 0, p.scale, KV + 64 * QS);
     __syncthreads();
-    if ((wave >> 1) == round) {
+    if (QT == 1) {
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int j = 0; j < NGMAX; ++j)
+        if (j < ng) qf[0][j] = *reinterpret_cast<const floatx4*>(KV + (wave * 32 + r32) * QS + 8 * j + 4 * hh);
+    } else if ((wave >> 1) == round) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int j = 0; j < NGMAX; ++j)
           if (j < ng) qf[qt][j] = *reinterpret_cast<const floatx4*>(KV + ((wave & 1) * 64 + qt * 32 + r32) * QS + 8 * j + 4 * hh);
     }
   }
-  int qreg[2];
-  qreg[0] = tok_reg[wave * 64 + r32];
-  qreg[1] = tok_reg[wave * 64 + 32 + r32];
+  int qreg[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) qreg[qt] = tok_reg[q0 + qt * 32 + r32];
 
-  floatx16 o[DT][2];
+  floatx16 o[DT][QT];
 #pragma unroll
   for (int i = 0; i < DT; ++i)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < QT; ++q)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[i][q][e] = 0.f;
-  float mrow[2] = {-3.0e38f, -3.0e38f}, lrow[2] = {0.f, 0.f};
+  float mrow[QT], lrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrow[qt] = -3.0e38f;
+    lrow[qt] = 0.f;
+  }
   const float* bias_h = p.bias + (size_t)head * N * N;
 
 #pragma unroll 1
@@ -132,9 +146,9 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
       const float* Kt = KV + (ks * 32) * QS;
       const float* Vt = KV + (64 + ks * 32) * QS;
       const int key0 = kt * 64 + ks * 32 + 4 * hh;  // + (e&3) + 8*(e>>2)
-      floatx16 s[2];
+      floatx16 s[QT];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[qt][e] = 0.f;
 #pragma unroll
@@ -145,13 +159,13 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
             for (int t = 0; t < 4; ++t) s[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], qf[qt][j][t], s[qt], 0, 0, 0);
           }
         }
-        const int q = wave * 64 + qt * 32 + r32;
+        const int q = q0 + qt * 32 + r32;
         float mx = -3.0e38f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = key0 + (e & 3) + 8 * (e >> 2);
           float v = s[qt][e] + bias_h[(size_t)key * N + q];
-          if (p.masked && tok_reg[key] != qreg[qt]) v += -100.0f;
+          if (use_mask && tok_reg[key] != qreg[qt]) v += -100.0f;
           s[qt][e] = v;
           mx = fmaxf(mx, v);
         }
@@ -178,17 +192,17 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void window_attn_kernel(Win
         for (int e = 0; e < 16; ++e) vv[e] = Vt[((e & 3) + 8 * (e >> 2) + 4 * hh) * QS + i * 32 + r32];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          o[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], s[0][e], o[i][0], 0, 0, 0);
-          o[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], s[1][e], o[i][1], 0, 0, 0);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) o[i][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], s[qt][e], o[i][qt], 0, 0, 0);
         }
       }
     }
   }
   // ---- normalise and store O^T: lane = query, registers = head-dim rows
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const float inv = 1.0f / (lrow[qt] + __shfl_xor(lrow[qt], 32, 64));
-    float* orow = p.out + (size_t)tok_pix[wave * 64 + qt * 32 + r32] * p.ldo + head * hd;
+    float* orow = p.out + (size_t)tok_pix[q0 + qt * 32 + r32] * p.ldo + head * hd;
 #pragma unroll
     for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -460,7 +474,7 @@ __global__ void pixel_mha_kernel(const float* __restrict__ qkv, int ldq, float* 
 #define ST ((hipStream_t)stream)
 
 extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* out, int ldo, int B, int H, int W,
-                                    int C, int heads, int ws, int shift, float scale, void* stream) {
+                                    int C, int heads, int ws, int shift, float scale, int variant, void* stream) {
   FFSR_CHECK(qkv && bias && out && B > 0 && heads > 0 && C % heads == 0);
   FFSR_CHECK(ws > 0 && H % ws == 0 && W % ws == 0 && (ws * ws) % 64 == 0 && ws * ws <= 256);
   FFSR_CHECK(shift >= 0 && shift < ws && ldq >= 3 * C && ldo >= C);
@@ -473,21 +487,28 @@ extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias
   FFSR_CHECK(N == 256);
   const size_t lds = (size_t)(128 * (a.hdp + 4) + 64) * 4 + 2 * N * 4;
   FFSR_CHECK(lds <= 160 * 1024);
-  dim3 grid(heads, (H / ws) * (W / ws) * B);
-  FFSR_CHECK(grid.y <= 65535);
   const int DT = (hd + 31) / 32;
-#define LAUNCH_WIN(D)                                                                                            \
-  {                                                                                                              \
-    if (lds > 64 * 1024)                                                                                         \
-      (void)hipFuncSetAttribute((const void*)window_attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                       \
-    hipLaunchKernelGGL(window_attn_kernel<D>, grid, dim3(256), lds, ST, a);                                      \
+  // QT = 1 (128 queries per workgroup, 2 workgroups per window-head) keeps the register file small enough for 2+
+  // waves per SIMD at the large head dims; QT = 2 loads K/V once per window-head (best for small head dims).
+  const int QT = (variant == 1 || variant == 2) ? variant : 1;   // measured: QT = 1 is 20-35 % faster at every head dim
+  dim3 grid(heads, (H / ws) * (W / ws) * B, QT == 1 ? 2 : 1);
+  FFSR_CHECK(grid.y <= 65535);
+#define LAUNCH_WIN(D, Q)                                                                                            \
+  {                                                                                                                 \
+    if (lds > 64 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)window_attn_kernel<D, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                          \
+    hipLaunchKernelGGL((window_attn_kernel<D, Q>), grid, dim3(256), lds, ST, a);                                     \
   }
-  switch (DT) {
-    case 1: LAUNCH_WIN(1); break;
-    case 2: LAUNCH_WIN(2); break;
-    case 3: LAUNCH_WIN(3); break;
-    default: LAUNCH_WIN(4); break;
+  switch (DT * 10 + QT) {
+    case 11: LAUNCH_WIN(1, 1); break;
+    case 12: LAUNCH_WIN(1, 2); break;
+    case 21: LAUNCH_WIN(2, 1); break;
+    case 22: LAUNCH_WIN(2, 2); break;
+    case 31: LAUNCH_WIN(3, 1); break;
+    case 32: LAUNCH_WIN(3, 2); break;
+    case 41: LAUNCH_WIN(4, 1); break;
+    default: LAUNCH_WIN(4, 2); break;
   }
 #undef LAUNCH_WIN
   return ffsr_launch_status();

@@ -352,12 +352,12 @@ def avgpool2(x, out=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention / scan
-def window_attn(qkv, bias, B, H, W, C, heads, ws, shift, scale, out=None):
+def window_attn(qkv, bias, B, H, W, C, heads, ws, shift, scale, out=None, variant=0):
     """qkv [B*H*W, 3C] -> [B*H*W, C]"""
     if out is None:
         out = torch.empty(B * H * W, C, device=qkv.device)
     hip.call("ffsr_window_attn_f32", _ptr(qkv), _mat(qkv)[3], _ptr(bias), _ptr(out), _mat(out)[3], B, H, W, C, heads,
-             ws, shift, float(scale), _stream())
+             ws, shift, float(scale), variant, _stream())
     return out
 
 

@@ -110,9 +110,10 @@ int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int B, int H, i
 
 /* DRCT (shifted) window attention, fused: softmax(q k^T * scale + bias (+ shift mask)) v.
  * qkv [B*H*W, ldq]: q | k | v, each [heads][C/heads]; bias dense, TRANSPOSED [heads, keys, queries] (ws = 16); roll / window
- * partition / reverse / mask folded into addressing.  Replaces drct_arch.py:175-206 and :376-414. */
+ * partition / reverse / mask folded into addressing.  variant: 0 = automatic, 1 / 2 = 128 / 256 queries per workgroup.
+ * Replaces drct_arch.py:175-206 and :376-414. */
 int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* out, int ldo, int B, int H, int W, int C,
-                         int heads, int ws, int shift, float scale, void* stream);
+                         int heads, int ws, int shift, float scale, int variant, void* stream);
 
 /* GRL 8x8 cosine window attention (mixed_attn_block_efficient.py:77-94,128-165) on the columns
  * [col0, col0 + 3*heads*hd) of qkv; biasT [heads, 64 keys, 64 queries] = 16*sigmoid(CPB-MLP) transposed;
