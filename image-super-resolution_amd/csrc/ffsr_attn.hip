@@ -12,7 +12,8 @@ namespace {
 
 // --------------------------------------------------------------------------------------------------------------
 // (1) DRCT window attention.  grid = (heads, windows*B), 256 threads.
-// qkv: [B*H*W, ldq] with q at col h*hd, k at C + h*hd, v at 2C + h*hd.  bias: [heads, N keys, N queries] dense.
+// qkv: [B*H*W, ldq] with q at col h*hd, k at C + h*hd, v at 2C + h*hd.  bias: the relative_position_bias_table
+// [(2ws-1)^2, heads] itself (gathered on the fly from an LDS copy of the head's column).
 // --------------------------------------------------------------------------------------------------------------
 struct WinArgs {
   const float* qkv;
@@ -31,33 +32,36 @@ __device__ __forceinline__ int region_id(int p, int n, int ws, int shift) {
 // product computed TRANSPOSED: S^T = K Q^T puts the query on the MFMA lane and the keys in the 16 accumulator
 // registers, so (a) the softmax row statistics are in-lane reductions plus one xor-32 exchange, and (b) the P^T tile
 // is already laid out as the B operand of O^T += V^T P^T -- probabilities never touch LDS.  Q fragments live in
-// registers; K / V tiles are staged through LDS once per workgroup.  biasT: [heads, N keys, N queries].
+// registers; K / V tiles are staged through LDS.
 template <int DT, int QT>  // DT = 32-wide head_dim tiles (hd <= 32*DT); QT = 32-query tiles per wave (WG = 128*QT queries)
 __global__ __launch_bounds__(256, (QT == 1 ? (DT == 1 ? 4 : (DT == 2 ? 3 : 2)) : (DT <= 2 ? 2 : 1))) void window_attn_kernel(WinArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NGMAX = 4 * DT;       // 8-wide k groups
-  const int N = p.ws * p.ws;          // tokens per window (256)
+  constexpr int WS = 16, N = WS * WS;  // window edge / tokens per window (checked by the launcher)
   const int QS = p.hdp + 4;           // LDS row stride (floats); (hdp+4)/4 is odd -> b128 reads conflict-free
   float* KV = lds;                    // [128][QS]: rows 0-63 K tile, 64-127 V tile (also Q staging) + 64 floats slack
   int* tok_pix = reinterpret_cast<int*>(KV + 128 * QS + 64);  // [N]
   int* tok_reg = tok_pix + N;                                  // [N]
+  float* rpb = reinterpret_cast<float*>(tok_reg + N);          // [(2ws-1)^2] relative position bias of this head
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x;
-  const int nwx = p.W / p.ws, nwy = p.H / p.ws;
+  const int nwx = p.W / WS, nwy = p.H / WS;
   const int win = blockIdx.y % (nwx * nwy), b = blockIdx.y / (nwx * nwy);
   const int wy = win / nwx, wx = win % nwx;
   for (int t = tid; t < N; t += 256) {
-    int py = t / p.ws, px = t % p.ws;
-    int ys = wy * p.ws + py, xs = wx * p.ws + px;  // position in the rolled image
+    int py = t / WS, px = t % WS;
+    int ys = wy * WS + py, xs = wx * WS + px;  // position in the rolled image
     int y = ys + p.shift, x = xs + p.shift;
     if (y >= p.H) y -= p.H;
     if (x >= p.W) x -= p.W;
     tok_pix[t] = (b * p.H + y) * p.W + x;
-    tok_reg[t] = p.masked ? region_id(ys, p.H, p.ws, p.shift) * 3 + region_id(xs, p.W, p.ws, p.shift) : 0;
+    tok_reg[t] = p.masked ? region_id(ys, p.H, WS, p.shift) * 3 + region_id(xs, p.W, WS, p.shift) : 0;
   }
   // only the windows of the last window row / column straddle regions of the shifted image
   const bool use_mask = p.masked && (wy == nwy - 1 || wx == nwx - 1);
+  const int span = 2 * WS - 1;
+  for (int t = tid; t < span * span; t += 256) rpb[t] = p.bias[(size_t)t * p.heads + head];
   const int hd = p.hd, hdp = p.hdp, ng = hdp >> 3;
   const int r32 = lane & 31, hh = lane >> 5;
   const float* qbase = p.qkv + head * hd;
@@ -133,7 +137,6 @@ __global__ __launch_bounds__(256, (QT == 1 ? (DT == 1 ? 4 : (DT == 2 ? 3 : 2)) :
     mrow[qt] = -3.0e38f;
     lrow[qt] = 0.f;
   }
-  const float* bias_h = p.bias + (size_t)head * N * N;
 
 #pragma unroll 1
   for (int kt = 0; kt < N / 64; ++kt) {
@@ -159,12 +162,14 @@ __global__ __launch_bounds__(256, (QT == 1 ? (DT == 1 ? 4 : (DT == 2 ? 3 : 2)) :
             for (int t = 0; t < 4; ++t) s[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], qf[qt][j][t], s[qt], 0, 0, 0);
           }
         }
+        // relative position bias: table[(qy - ky + ws-1) * (2ws-1) + (qx - kx + ws-1)]  (drct_arch.py:148-158,188-191)
         const int q = q0 + qt * 32 + r32;
+        const int qidx = (q / WS + WS - 1) * span + (q % WS) + WS - 1;
         float mx = -3.0e38f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = key0 + (e & 3) + 8 * (e >> 2);
-          float v = s[qt][e] + bias_h[(size_t)key * N + q];
+          float v = s[qt][e] + rpb[qidx - (key / WS) * span - (key % WS)];
           if (use_mask && tok_reg[key] != qreg[qt]) v += -100.0f;
           s[qt][e] = v;
           mx = fmaxf(mx, v);
@@ -484,8 +489,8 @@ extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias
   a.qkv = qkv; a.bias = bias; a.out = out; a.ldq = ldq; a.ldo = ldo; a.C = C; a.H = H; a.W = W; a.ws = ws;
   a.shift = shift; a.heads = heads; a.hd = hd; a.hdp = (hd + 7) / 8 * 8; a.masked = shift > 0; a.scale = scale;
   const int N = ws * ws;
-  FFSR_CHECK(N == 256);
-  const size_t lds = (size_t)(128 * (a.hdp + 4) + 64) * 4 + 2 * N * 4;
+  FFSR_CHECK(ws == 16);
+  const size_t lds = (size_t)(128 * (a.hdp + 4) + 64) * 4 + 2 * N * 4 + (size_t)(2 * ws - 1) * (2 * ws - 1) * 4;
   FFSR_CHECK(lds <= 160 * 1024);
   const int DT = (hd + 31) / 32;
   // QT = 1 (128 queries per workgroup, 2 workgroups per window-head) keeps the register file small enough for 2+

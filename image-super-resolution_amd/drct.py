@@ -12,12 +12,6 @@ from .common import SRTail, dev, to_map, tokens
 from .ops import ACT_GELU, ACT_LRELU
 
 
-def _rel_index(ws):
-    c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
-    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
-    return (rel[..., 0] * (2 * ws - 1) + rel[..., 1]).reshape(-1)
-
-
 class _Swin:
     def __init__(self, sd, p, device, dim, heads, ws, shift):
         self.dim, self.heads, self.ws, self.shift = dim, heads, ws, shift
@@ -27,9 +21,7 @@ class _Swin:
         self.proj = ops.pack_conv(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], device)
         self.fc1 = ops.pack_conv(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], device)
         self.fc2 = ops.pack_conv(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], device)
-        N = ws * ws
-        table = sd[p + "attn.relative_position_bias_table"].float()
-        self.bias = dev(table[_rel_index(ws)].reshape(N, N, heads).permute(2, 1, 0), device)   # [heads, keys, queries]
+        self.bias = dev(sd[p + "attn.relative_position_bias_table"], device)     # [(2ws-1)^2, heads], gathered in-kernel
         self.scale = (dim // heads) ** -0.5
 
     def __call__(self, x, B, H, W):

@@ -109,7 +109,7 @@ int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int B, int H, i
                   int do_clamp, void* stream);
 
 /* DRCT (shifted) window attention, fused: softmax(q k^T * scale + bias (+ shift mask)) v.
- * qkv [B*H*W, ldq]: q | k | v, each [heads][C/heads]; bias dense, TRANSPOSED [heads, keys, queries] (ws = 16); roll / window
+ * qkv [B*H*W, ldq]: q | k | v, each [heads][C/heads]; bias = relative_position_bias_table [(2ws-1)^2, heads] (ws = 16); roll / window
  * partition / reverse / mask folded into addressing.  variant: 0 = automatic, 1 / 2 = 128 / 256 queries per workgroup.
  * Replaces drct_arch.py:175-206 and :376-414. */
 int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* out, int ldo, int B, int H, int W, int C,

@@ -160,8 +160,10 @@ def test_uint8_boundary(ops):
 def test_window_attn(ops, C, heads, shift, H, W):
     from ffsr_oracle.common import win_split, win_merge, shift_mask
     B, ws, hd = 2, 16, C // heads
+    from ffsr_oracle.drct import rel_pos_index
     qkv = rnd(B * H * W, 3 * C, seed=1)
-    bias = rnd(heads, 256, 256, seed=2)
+    table = rnd(31 * 31, heads, seed=2)
+    bias = table[rel_pos_index(16).reshape(-1)].reshape(256, 256, heads).permute(2, 0, 1)     # [heads, q, k]
     t = qkv.reshape(B, H, W, 3 * C)
     if shift:
         t = torch.roll(t, (-shift, -shift), (1, 2))
@@ -173,7 +175,7 @@ def test_window_attn(ops, C, heads, shift, H, W):
     o = win_merge((a.softmax(-1) @ w[2]).transpose(1, 2).reshape(-1, 256, C), ws, ws, H, W)
     if shift:
         o = torch.roll(o, (shift, shift), (1, 2))
-    got = ops.window_attn(qkv.to(DEV), bias.transpose(1, 2).contiguous().to(DEV), B, H, W, C, heads, ws, shift, hd ** -0.5)
+    got = ops.window_attn(qkv.to(DEV), table.to(DEV), B, H, W, C, heads, ws, shift, hd ** -0.5)
     close(got.cpu(), o.reshape(B * H * W, C), 2e-5, "window attention")
 
 

@@ -7,7 +7,7 @@ C, heads, shift, reps = (int(v) for v in sys.argv[1:5])
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 B, H, W = 1, 352, 512
 qkv = torch.randn(B * H * W, 3 * C, device="cuda")
-bias = torch.randn(heads, 256, 256, device="cuda")
+bias = torch.randn(31 * 31, heads, device="cuda")
 out = ops.window_attn(qkv, bias, B, H, W, C, heads, 16, shift, (C // heads) ** -0.5, variant=variant)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
