@@ -36,9 +36,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s measured achievable)
 
 
-def synth_lr(seed, h, w):
+def synth_lr(seed, h, w, b=1):
     g = torch.Generator().manual_seed(seed)
-    x = torch.rand(1, 3, h, w, generator=g)
+    x = torch.rand(b, 3, h, w, generator=g)
     x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (2, 2, 2, 2), mode="reflect"), 5, 1)
     x = (x - x.amin()) / (x.amax() - x.amin())
     return torch.floor(x * 256).clamp(0, 255) / 255.0
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=H_LR)
     ap.add_argument("--width", type=int, default=W_LR)
+    ap.add_argument("--batch", type=int, default=1, help="images per step per GPU (BASELINE config 3 uses 16 x 64x64)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=None, help="GEMM arithmetic (default: the engine's default)")
@@ -88,15 +90,17 @@ def main():
     if world != args.gpus:
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if "FFSR_BENCH_DEVICE" in os.environ:        # rehearsal: several ranks on one card
+        local = int(os.environ["FFSR_BENCH_DEVICE"])
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    S.init_process_group("nccl")
+    S.init_process_group(args.backend)
 
     weights = W.random_weights(seed=0, small=args.small)
     weights = S.broadcast_weights(weights, device)          # RCCL over xGMI, rank 0's values win (no-op at N=1)
     eng = E.Engine(weights, device)
     h, w = args.height, args.width
-    lrs = [E.nchw_to_map(synth_lr(1234 + rank * 1000 + i, h, w), device) for i in range(max(1, min(args.steps, 4)))]
+    lrs = [E.nchw_to_map(synth_lr(1234 + rank * 1000 + i, h, w, args.batch), device) for i in range(max(1, min(args.steps, 4)))]
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -126,7 +130,7 @@ def main():
     log(f"timed {args.steps} steps: {1e3 * dt / args.steps:.1f} ms/step")
 
     mp_per_image = (h * SCALE) * (w * SCALE) / 1e6
-    value = world * args.steps * mp_per_image / dt
+    value = world * args.steps * args.batch * mp_per_image / dt
 
     # ---- roofline of the dominant kernel: one extra instrumented step on the same stream
     # (experts run one after the other here: with the four expert streams overlapping, an event pair around one
@@ -194,13 +198,13 @@ def main():
                      "kernel_share_of_step": conv_s / step_s})
 
     if rank == 0:
-        line = {"metric": "SR output megapixels/s (x4, 510x340 LR -> 2040x1360, full 4-expert + 7-phase fusion)",
+        line = {"metric": f"SR output megapixels/s (x4, {w}x{h} LR -> {w * SCALE}x{h * SCALE}, full 4-expert + 7-phase fusion)",
                 "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (GEMM/conv products as 3-term split-bf16 MFMA, fp32 accumulate)", "data": "synthetic (seeded LR images; random-init weights of the exact architecture)",
                 "config": {"workload": f"CompleteEnhancedFusionSR hot path: {w}x{h} LR image per step per GPU "
-                                       f"(pad16 -> DRCT-L + GRL-B + NAFNet-w64 + MambaIR -> fusion), batch 1",
-                           "lr_hw": [h, w], "images_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}",
+                                       f"(pad16 -> DRCT-L + GRL-B + NAFNet-w64 + MambaIR -> fusion), batch {args.batch}",
+                           "lr_hw": [h, w], "images_per_step_per_gpu": args.batch, "parallelism": f"image-parallel x{world}",
                            "small_experts": bool(args.small)},
                 "gemm_mode": ops.GEMM_MODE, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,10 @@ class Engine:
     def __init__(self, weights: Dict[str, dict], device=None, scale=4):
         self.device = require_gpu(device)
         self.scale = scale
+        # weight preparation (packing, BN folding, bias tables) is host code: normalise to CPU fp32 first
+        # (after shard.broadcast_weights the tensors live on the device)
+        weights = {m: {k: v.detach().to(device="cpu", dtype=torch.float32) if v.is_floating_point() else v.cpu()
+                       for k, v in sd.items()} for m, sd in weights.items()}
         with torch.cuda.device(self.device):
             self.drct = DRCT(weights["drct"], self.device)
             self.grl = GRL(weights["grl"], self.device)
