@@ -170,6 +170,20 @@ __global__ void edge_final_kernel(const float* __restrict__ sr, int lds, const f
   }
 }
 
+// SSIM map of calculate_ssim_torch (src/utils/metrics.py:129-186): inputs are the Gaussian-filtered moments
+// mu1, mu2, E[x1^2], E[x2^2], E[x1 x2] (one channel each); out = ((2 mu1 mu2 + C1)(2 s12 + C2)) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2))
+__global__ void ssim_map_kernel(const float* __restrict__ mu1, const float* __restrict__ mu2, const float* __restrict__ e11,
+                                const float* __restrict__ e22, const float* __restrict__ e12, int ld, float* __restrict__ out,
+                                int ldo, long long M) {
+  long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  const float a = mu1[m * ld], b = mu2[m * ld];
+  const float a2 = a * a, b2 = b * b, ab = a * b;
+  const float s1 = e11[m * ld] - a2, s2 = e22[m * ld] - b2, s12 = e12[m * ld] - ab;
+  out[m * ldo] = ((2.f * ab + C1) * (2.f * s12 + C2)) / ((a2 + b2 + C1) * (s1 + s2 + C2));
+}
+
 inline int grid_for(long long n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -207,5 +221,12 @@ extern "C" int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, 
   FFSR_CHECK(sr && edge && gate && strength && lr && rscale && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0);
   hipLaunchKernelGGL(edge_final_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, sr, lds, edge, lde, gate, ldg,
                      strength, lr, ldl, rscale, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12,
+                                 int ld, float* out, int ldo, long long M, void* stream) {
+  FFSR_CHECK(mu1 && mu2 && e11 && e22 && e12 && out && M > 0 && ld > 0 && ldo > 0);
+  hipLaunchKernelGGL(ssim_map_kernel, dim3(grid_for(M)), dim3(256), 0, ST, mu1, mu2, e11, e22, e12, ld, out, ldo, M);
   return ffsr_launch_status();
 }

@@ -489,11 +489,15 @@ def pad_reflect(x, Hp, Wp):
     return out
 
 
-def crop(x, Ho, Wo, clamp=False, out=None):
+def crop(x, Ho, Wo, clamp=False, out=None, y0=0, x0=0):
+    """window [y0:y0+Ho, x0:x0+Wo] of every image (compacting copy), optionally clamped to [0, 1]"""
     B, H, W, C = x.shape
+    assert y0 + Ho <= H and x0 + Wo <= W
     if out is None:
         if (Ho, Wo) == (H, W) and not clamp:
             return x
         out = new_map(B, Ho, Wo, C, x.device)
-    hip.call("ffsr_crop_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, H, W, Ho, Wo, C, int(clamp), _stream())
+    s = ld(x)
+    hip.call("ffsr_crop_f32", x.data_ptr() + 4 * (y0 * W + x0) * s, s, _ptr(out), ld(out), B, H, W, Ho, Wo, C,
+             int(clamp), _stream())
     return out

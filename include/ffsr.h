@@ -174,6 +174,10 @@ int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, co
                         const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo, int B,
                         int h, int w, int Hh, int Wh, void* stream);
 
+/* SSIM map from Gaussian-filtered moments (src/utils/metrics.py:129-186, calculate_ssim_torch); one channel, stride ld. */
+int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12, int ld,
+                      float* out, int ldo, long long M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,3 +161,18 @@ def test_full_depth_experts_and_fusion_vs_oracle_64x64(mode):
     for n, (e_sr, e_feat) in report.items():
         assert e_sr < TOL, (mode, n, e_sr, e_feat)
     assert final < TOL, (mode, final)
+
+
+def test_device_metrics_match_reference_formulas():
+    """BT.601-Y PSNR / SSIM with 4 px crop (metrics.py:30-186), device vs CPU oracle."""
+    from ffsr_oracle import metrics as om
+    M, E = mod("metrics"), mod("engine")
+    g = torch.Generator().manual_seed(8)
+    hr = torch.rand(1, 3, 72, 100, generator=g)
+    sr = (hr + 0.05 * torch.randn(hr.shape, generator=g)).clamp(-0.1, 1.1)
+    a, b = E.nchw_to_map(sr, DEV), E.nchw_to_map(hr, DEV)
+    for crop, y in ((4, True), (0, False)):
+        assert abs(M.psnr(a, b, crop, y) - om.psnr(sr, hr, crop, y)) < 1e-3
+    assert abs(M.ssim(a, b, 4, True) - om.ssim(sr, hr, 4, True)) < 1e-5
+    assert abs(M.ssim(a, b, 0, False) - om.ssim(sr, hr, 0, False)) < 1e-5
+    assert M.psnr(b, b, 4, True) == float("inf")
