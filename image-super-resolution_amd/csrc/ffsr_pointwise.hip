@@ -411,6 +411,24 @@ __global__ void crop_kernel(const float* __restrict__ in, int ldi, float* __rest
   out[pix * ldo + c] = v;
 }
 
+// out[b, i, j, c] (+)= scale * in[b, ay_i*i + ay_j*j + cy, ax_i*i + ax_j*j + cx, c]: flips / rot90 of the 8-fold
+// geometric self-ensemble (scripts/extract_test_tta_cache.py:97-104, scripts/generate_fast_submission.py:55-61)
+__global__ void dihedral_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int Hi, int Wi,
+                                int Ho, int Wo, int C, int ay_i, int ay_j, int cy, int ax_i, int ax_j, int cx, float scale,
+                                int accumulate) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * Ho * Wo * C) return;
+  int c = (int)(idx % C);
+  long long pix = idx / C;
+  int j = (int)(pix % Wo);
+  long long t = pix / Wo;
+  int i = (int)(t % Ho), b = (int)(t / Ho);
+  int y = ay_i * i + ay_j * j + cy, x = ax_i * i + ax_j * j + cx;
+  float v = in[(((size_t)b * Hi + y) * Wi + x) * ldi + c] * scale;
+  float* o = out + pix * ldo + c;
+  *o = accumulate ? *o + v : v;
+}
+
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -559,5 +577,21 @@ extern "C" int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int 
   FFSR_CHECK(in && out && B > 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W && C > 0);
   hipLaunchKernelGGL(crop_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, Ho,
                      Wo, C, do_clamp);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_dihedral_f32(const float* in, int ldi, float* out, int ldo, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                 int ay_i, int ay_j, int cy, int ax_i, int ax_j, int cx, float scale, int accumulate,
+                                 void* stream) {
+  FFSR_CHECK(in && out && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0);
+  // the four corners of the output must map inside the input
+  const int is[2] = {0, Ho - 1}, js[2] = {0, Wo - 1};
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      int y = ay_i * is[a] + ay_j * js[b] + cy, x = ax_i * is[a] + ax_j * js[b] + cx;
+      FFSR_CHECK(y >= 0 && y < Hi && x >= 0 && x < Wi);
+    }
+  hipLaunchKernelGGL(dihedral_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi,
+                     Wi, Ho, Wo, C, ay_i, ay_j, cy, ax_i, ax_j, cx, scale, accumulate);
   return ffsr_launch_status();
 }

@@ -91,6 +91,17 @@ class Engine:
             imgs, feats = self.run_experts(lr)
             return self.fusion(lr, imgs, feats)
 
+    def process_tta(self, lr):
+        """8x geometric self-ensemble: mean over {hflip} x {rot90^k} of the de-transformed outputs,
+        clamped (scripts/extract_test_tta_cache.py:253-256, scripts/generate_fast_submission.py:235-250)."""
+        with torch.cuda.device(self.device):
+            acc = None
+            for hflip in (False, True):
+                for rot in range(4):
+                    sr = self.process(ops.dihedral(lr, hflip, rot))
+                    acc = ops.dihedral(sr, hflip, rot, inverse=True, out=acc, scale=0.125, accumulate=acc is not None)
+            return ops.unary(acc, clamp=(0.0, 1.0), out=acc)
+
     # -------------------------------------------------------------------------------------- uint8 boundary
     def upload(self, img_u8: np.ndarray) -> torch.Tensor:
         """uint8 HxWx3 RGB (host) -> float map [1,h,w,3] on the device (io._uint2tensor4)."""

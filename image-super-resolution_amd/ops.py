@@ -501,3 +501,35 @@ def crop(x, Ho, Wo, clamp=False, out=None, y0=0, x0=0):
     hip.call("ffsr_crop_f32", x.data_ptr() + 4 * (y0 * W + x0) * s, s, _ptr(out), ld(out), B, H, W, Ho, Wo, C,
              int(clamp), _stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------- geometric TTA
+def _rot_map(k, h, w):
+    """torch.rot90(x, k, [H, W]) as out[i, j] = x[f(i, j)] for an input of size h x w -> (f, (out_h, out_w))"""
+    k %= 4
+    if k == 0:
+        return (lambda i, j: (i, j)), (h, w)
+    if k == 1:
+        return (lambda i, j: (j, w - 1 - i)), (w, h)
+    if k == 2:
+        return (lambda i, j: (h - 1 - i, w - 1 - j)), (h, w)
+    return (lambda i, j: (h - 1 - j, i)), (w, h)
+
+
+def dihedral(x, hflip: bool, rot: int, inverse=False, out=None, scale=1.0, accumulate=False):
+    """forward: hflip (flip W) then rot90 x rot (scripts/extract_test_tta_cache.py:97-104);
+    inverse: rot90 x (-rot) then hflip (scripts/generate_fast_submission.py:55-61).  x [B,H,W,C] map."""
+    B, H, W, C = x.shape
+    if not inverse:
+        rmap, (Ho, Wo) = _rot_map(rot, H, W)
+        f = (lambda i, j: (lambda y, xx: (y, W - 1 - xx))(*rmap(i, j))) if hflip else rmap
+    else:
+        rmap, (Ho, Wo) = _rot_map(-rot, H, W)
+        f = (lambda i, j: rmap(i, Wo - 1 - j)) if hflip else rmap
+    (cy, cx), (y1, x1), (y2, x2) = f(0, 0), f(1, 0), f(0, 1)
+    if out is None:
+        out = new_map(B, Ho, Wo, C, x.device)
+    assert tuple(out.shape) == (B, Ho, Wo, C)
+    hip.call("ffsr_dihedral_f32", _ptr(x), ld(x), _ptr(out), ld(out), B, H, W, Ho, Wo, C, y1 - cy, y2 - cy, cy, x1 - cx,
+             x2 - cx, cx, float(scale), int(accumulate), _stream())
+    return out

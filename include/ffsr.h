@@ -108,6 +108,11 @@ int ffsr_pad_reflect_f32(const float* in, int ldi, float* out, int ldo, int B, i
 int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Ho, int Wo, int C,
                   int do_clamp, void* stream);
 
+/* out[b,i,j,:] (+)= scale * in[b, ay_i*i + ay_j*j + cy, ax_i*i + ax_j*j + cx, :] -- the hflip / rot90 index maps of the
+ * 8x geometric self-ensemble (scripts/extract_test_tta_cache.py:97-104; generate_fast_submission.py:55-61,250). */
+int ffsr_dihedral_f32(const float* in, int ldi, float* out, int ldo, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                      int ay_i, int ay_j, int cy, int ax_i, int ax_j, int cx, float scale, int accumulate, void* stream);
+
 /* DRCT (shifted) window attention, fused: softmax(q k^T * scale + bias (+ shift mask)) v.
  * qkv [B*H*W, ldq]: q | k | v, each [heads][C/heads]; bias = relative_position_bias_table [(2ws-1)^2, heads] (ws = 16); roll / window
  * partition / reverse / mask folded into addressing.  variant: 0 = automatic, 1 / 2 = 128 / 256 queries per workgroup.

@@ -176,3 +176,37 @@ def test_device_metrics_match_reference_formulas():
     assert abs(M.ssim(a, b, 4, True) - om.ssim(sr, hr, 4, True)) < 1e-5
     assert abs(M.ssim(a, b, 0, False) - om.ssim(sr, hr, 0, False)) < 1e-5
     assert M.psnr(b, b, 4, True) == float("inf")
+
+
+def test_dihedral_maps_match_torch():
+    E, ops = mod("engine"), mod("ops")
+    x = torch.arange(2 * 3 * 5 * 7, dtype=torch.float32).reshape(2, 3, 5, 7)
+    xm = E.nchw_to_map(x, DEV)
+    for hflip in (False, True):
+        for rot in range(4):
+            fwd = torch.rot90(torch.flip(x, [3]) if hflip else x, rot, [2, 3])
+            got = E.map_to_nchw(ops.dihedral(xm, hflip, rot))
+            assert torch.equal(got, fwd), (hflip, rot)
+            back = E.map_to_nchw(ops.dihedral(ops.dihedral(xm, hflip, rot), hflip, rot, inverse=True))
+            assert torch.equal(back, x), (hflip, rot)
+
+
+def test_tta_x8_vs_oracle():
+    """8x geometric self-ensemble through Engine.process_tta vs the oracle with torch flips / rot90."""
+    from ffsr_oracle import pipeline
+    from ffsr_oracle.scan_c import selective_scan_c
+    W, E = mod("weights"), mod("engine")
+    weights = W.random_weights(seed=70, small=True)
+    eng = E.Engine(weights, DEV)
+    lr = lr_image(16, 1, 24, 40)
+    cfg = dict(enc_blks=(1, 1, 1, 1), mid_blks=1, dec_blks=(1, 1, 1, 1))
+    outs = []
+    for hflip in (False, True):
+        for rot in range(4):
+            v = torch.rot90(torch.flip(lr, [3]) if hflip else lr, rot, [2, 3])
+            sr = pipeline.process_image(weights, v, naf_cfg=cfg, scan_fn=selective_scan_c)
+            sr = torch.rot90(sr, -rot, [2, 3])
+            outs.append(torch.flip(sr, [3]) if hflip else sr)
+    want = torch.stack(outs).mean(0).clamp(0, 1)
+    got = E.map_to_nchw(eng.process_tta(E.nchw_to_map(lr, DEV)))
+    assert err(got, want) < TOL, err(got, want)
