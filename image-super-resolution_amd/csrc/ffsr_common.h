@@ -50,3 +50,24 @@ __device__ __forceinline__ float wave_max(float v) {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ---- split-bf16 planes: x ~ hi + lo with hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  Two values per call
+// (packed pairs: low half = first value).
+typedef __bf16 ffsr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ffsr_floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned ffsr_uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ffsr_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const ffsr_floatx2 x = {x0, x1};
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, ffsr_bf16x2));
+  const ffsr_floatx2 r = {x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u)};
+  hi = h;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ffsr_bf16x2));
+}
+// 8 consecutive channels of one row -> 16 bytes of the hi plane and 16 bytes of the lo plane
+__device__ __forceinline__ void ffsr_store_planes8(unsigned short* hi, unsigned short* lo, const float* v) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) ffsr_split2(v[2 * c], v[2 * c + 1], h[c], l[c]);
+  *reinterpret_cast<ffsr_uintx4*>(hi) = ffsr_uintx4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<ffsr_uintx4*>(lo) = ffsr_uintx4{l[0], l[1], l[2], l[3]};
+}

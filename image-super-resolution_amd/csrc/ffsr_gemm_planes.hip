@@ -1,0 +1,479 @@
+// Implicit-GEMM convolution / token GEMM whose A operand arrives PRE-SPLIT: two bf16 planes (hi = bf16(x),
+// lo = bf16(x - hi)) of shape [pixels, Cp] (Cp % 32 == 0, pad channels zero) instead of one fp32 matrix.  Same bytes in
+// HBM as fp32, same arithmetic as ffsr_conv2d_bf16x3 (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32
+// accumulate) -- but the main loop has NO vector ALU work and NO LDS stores: both operands go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4), S stages deep, counted s_waitcnt vmcnt + one raw s_barrier per 32-deep K step.
+//
+//   out[m, n] = res[m, n] * rvec[n] * rscale + act(sum_k A[m, k] * Wt[n, k] + bias[n]) * cvec[n] * cscale
+//   A[m, (tap, c)] = in[pixel(m) + tap offset, c]   (zero page for out-of-image taps / rows >= M)
+//
+// Tile: BM x BN (BM = 128 / 256, BN = 64 / 128 / 192 / 256), BM/64 x 2 waves, wave tile 64 x BN/2 (2 x TN MFMA tiles of
+// 32x32).  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
+// ~16 B/clk/CU), not the matrix pipe, is what bounds the 128-row tile on long-K shapes.
+// LDS image of one stage: A_hi | A_lo | B_hi | B_lo, rows of 64 B (32 bf16), no padding: one LDS-DMA instruction
+// writes 16 rows x 64 B lane-linear.  Bank conflicts are removed on the SOURCE side: the 16-byte chunk c of row r is
+// stored in slot c ^ ((r >> 2) & 3) of its row (each lane fetches the chunk that belongs in its slot), and the
+// fragment reads apply the same XOR -> every ds_read_b128 lane group covers 16 distinct 16-byte slots of the bank row.
+// Epilogue: accumulator tiles are transposed through the (idle) staging LDS so that every lane owns 8 consecutive
+// columns of one row: fp32 output as 16-byte stores and/or bf16 hi/lo planes as 16-byte stores (for the next GEMM).
+#include "ffsr_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct PlaneArgs {
+  const unsigned short* a_hi;   // [B*H*W][Cp]
+  const unsigned short* a_lo;
+  const unsigned short* w_hi;   // [Npad][taps*Cp]
+  const unsigned short* w_lo;
+  const unsigned short* zeros;  // >= 64 B of zeros
+  const float* bias;
+  float* out;                   // fp32 output [M][ldo] or null
+  const float* res;
+  const float* cvec;
+  const float* rvec;
+  unsigned short* o_hi;         // plane output [M][ldp] or null
+  unsigned short* o_lo;
+  int B, H, W, Cp;
+  int N, Ho, Wo, ldo, ldr, ldp;
+  int KH, KW, stride, pad_h, pad_w;
+  int act;
+  float slope, cscale, rscale;
+  int M, nk;                    // nk = taps * Cp / 32
+};
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) { ffsr_split2(x0, x1, hi, lo); }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+constexpr int pieces_in_group(int g, int groups, int loads) {
+  int n = 0;
+  for (int idx = 0; idx < loads; ++idx) n += (idx * groups / loads == g);
+  return n;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// GELU: exact-erf GELU epilogue; otherwise the epilogue activation is v > 0 ? v : v * slope (none: slope 1, ReLU: 0).
+// SCHED 1: the LDS-DMA pieces of the next K step are issued one at a time between the MFMA triples of the current step
+// (a burst of 10 pieces right after the barrier costs 100-185 issue cycles each with the matrix pipe idle).
+template <int BM, int BN, int STAGES, bool GELU, int SCHED>
+__global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
+  constexpr int NW = BM / 32;                                // waves: (BM / 64) x 2
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;        // bytes of one plane of one stage
+  constexpr int STAGE = 2 * (PLANE_A + PLANE_B);
+  constexpr int NB = (BN / 16 + NW - 1) / NW;                // B pieces (LDS-DMA instructions) per wave and plane
+  constexpr bool B_EVEN = (BN / 16) % NW == 0;               // every wave owns NB pieces (else the last round is partial)
+  constexpr int LOADS = 2 * (2 + NB);                        // LDS-DMA instructions per wave and K step (full waves)
+  static_assert(STAGES == 2 || B_EVEN, "counted vmcnt needs the same number of loads in every wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // STAGES * STAGE bytes (>= 4 * 9216 for the epilogue)
+
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+  const int tile = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (orig >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 2;                                // row inside a 16-row LDS-DMA piece
+
+  // ---- A loader state: this lane fetches rows 32*wave + lrow and + 16 (pieces 2*wave, 2*wave + 1) of both planes
+  const int ntap = p.KH * p.KW;
+  const int HoWo = p.Ho * p.Wo;
+  unsigned a_off[2];     // byte offset of (pixel of tap (0,0), chunk slot of this lane) in a plane
+  unsigned a_mask[2];    // bit t = tap t is inside the image
+  const ptrdiff_t lo_delta = reinterpret_cast<const unsigned char*>(p.a_lo) - reinterpret_cast<const unsigned char*>(p.a_hi);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 32 * wave + 16 * i + lrow;
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int m = m0 + row;
+    a_off[i] = 0;
+    a_mask[i] = 0;
+    if (m < p.M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+      a_off[i] = (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.Cp + chunk * 8) * 2u;   // may wrap for negative iy0/ix0: only used when the tap is valid
+      unsigned mk = 0;
+      for (int t = 0; t < ntap; ++t) {
+        const int yy = iy0 + t / p.KW, xx = ix0 + t % p.KW;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
+    }
+  }
+  // ---- B loader state: rows 16*(wave + NW*j) + lrow of the BN-row tile
+  unsigned b_off[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int row = 16 * (wave + NW * j) + lrow;
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    b_off[j] = (unsigned)((n0 + row) * (p.nk * 32) + chunk * 8) * 2u;
+  }
+
+  // issue position (advanced once per issued K step): tap, 32-channel chunk inside the tap, tap pixel offset
+  int i_tap = 0, i_cc = 0, i_ky = 0, i_kx = 0;
+  const int cpt = p.Cp >> 5;
+  unsigned i_koff = 0;   // byte offset of K step in a weight row
+  // one LDS-DMA piece of K step (i_tap, i_cc): idx 0..3 = A (row block idx>>1, plane idx&1), 4.. = B (piece (idx-4)>>1, plane)
+  auto issue_piece = [&](int stage, int idx, bool valid) {
+    unsigned char* base = smem + stage * STAGE;
+    if (idx < 4) {
+      const int i = idx >> 1;
+      const unsigned toff = (unsigned)((i_ky * p.W + i_kx) * p.Cp + i_cc * 32) * 2u;
+      const bool ok = valid && ((a_mask[i] >> i_tap) & 1u);
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.a_hi) + (size_t)(a_off[i] + toff);
+      if (idx & 1) src += lo_delta;
+      src = ok ? src : reinterpret_cast<const unsigned char*>(p.zeros);
+      unsigned char* dst = base + (2 * wave + i) * 1024 + (idx & 1) * PLANE_A;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+    } else {
+      const int j = (idx - 4) >> 1;
+      if (!B_EVEN && j == NB - 1 && wave + NW * j >= BN / 16) return;   // wave-uniform
+      const size_t o = (size_t)b_off[j] + i_koff;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>((idx & 1) ? p.w_lo : p.w_hi) + o;
+      src = valid ? src : reinterpret_cast<const unsigned char*>(p.zeros);
+      unsigned char* dst = base + 2 * PLANE_A + (wave + NW * j) * 1024 + (idx & 1) * PLANE_B;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    i_koff += 64;
+    if (++i_cc == cpt) {
+      i_cc = 0;
+      ++i_tap;
+      if (++i_kx == p.KW) { i_kx = 0; ++i_ky; }
+    }
+  };
+  auto issue = [&](int stage, bool valid) {
+#pragma unroll
+    for (int idx = 0; idx < LOADS; ++idx) issue_piece(stage, idx, valid);
+    advance();
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (BN / 2);
+  const int r = lane & 31, h = lane >> 5;
+  const int swz = (r >> 2) & 3;
+  const int fo0 = r * 64 + (((0 + h) ^ swz) << 4);   // fragment byte offsets inside a 32-row block, K half 0 / 1
+  const int fo1 = r * 64 + (((2 + h) ^ swz) << 4);
+  const int nk = p.nk;
+
+  // ---- prologue: STAGES - 1 K steps in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s, s < nk);   // (steps past nk fetch the zero page: same vmcnt bookkeeping)
+
+  int cs = 0;                 // stage being computed
+  int is = STAGES - 1;        // stage being filled
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire K step kt: STAGES - 2 younger steps stay in flight (steps past nk are zero-page fetches)
+    wait_vmcnt<(STAGES - 2) * LOADS>();
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of step kt have landed; every wave is done reading stage `is`
+    const bool more = kt + STAGES - 1 < nk;
+    if (SCHED == 0) issue(is, more);
+
+    const unsigned char* A = smem + cs * STAGE + wrow * 64;
+    const unsigned char* Bt = smem + cs * STAGE + 2 * PLANE_A + wcol * 64;
+    if (++cs == STAGES) cs = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = ks ? fo1 : fo0;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(A + i * 2048 + fo);
+        al[i] = *reinterpret_cast<const bf16x8*>(A + PLANE_A + i * 2048 + fo);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(Bt + j * 2048 + fo);
+        bl[j] = *reinterpret_cast<const bf16x8*>(Bt + PLANE_B + j * 2048 + fo);
+      }
+      static_for<0, TM * TN>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        if constexpr (SCHED == 1) {
+          constexpr int GROUPS = 2 * TM * TN;
+          const int g = ks * TM * TN + t;                       // MFMA triple index inside the K step
+          // spread the LOADS pieces over the GROUPS triples
+#pragma unroll
+          for (int idx = 0; idx < LOADS; ++idx)
+            if (idx * GROUPS / LOADS == g) issue_piece(is, idx, more);
+          __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);      // 3 MFMA, then this triple's pieces
+          constexpr int c0 = pieces_in_group(t, GROUPS, LOADS), c1 = pieces_in_group(TM * TN + t, GROUPS, LOADS);
+          if (ks == 0) { if constexpr (c0 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c0, 0); }
+          else { if constexpr (c1 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c1, 0); }
+        }
+      });
+    }
+    if (SCHED == 1) advance();
+    if (++is == STAGES) is = 0;
+  }
+  wait_vmcnt<0>();                // zero-page fetches of the last steps
+  __builtin_amdgcn_s_barrier();   // all fragment reads done: the staging LDS becomes the transpose scratch
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+  // Per 32x32 tile: bias / activation / column scale in the accumulator layout (column = lane), transpose through a
+  // 32 x 36-float scratch of this wave, then lane = (row 16*pass + lane/4, columns 8*(lane&3) .. +7).
+  float* T = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+  const int erow = lane >> 2, ecol = (lane & 3) * 8;
+  const int ldp = p.ldp;
+  // wave-uniform: may the 8-column groups use 16-byte accesses?
+  const bool vec_ok = (!p.out || ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0)) &&
+                      (!p.res || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)) &&
+                      (!p.rvec || (reinterpret_cast<uintptr_t>(p.rvec) & 15) == 0);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int ncol = n0 + wcol + jn * 32;          // first column of this tile
+    if (ncol >= p.N && ncol >= ldp) continue;      // wave-uniform: nothing to write
+    const int nc = min(ncol + r, p.N - 1);
+    const float bia = p.bias ? p.bias[nc] : 0.f;
+    const float cs_ = (p.cvec ? p.cvec[nc] : 1.f) * p.cscale;
+    const int nn = ncol + ecol;                    // first of this lane's 8 output columns
+    const bool fast = vec_ok && nn + 8 <= p.N;
+    floatx4 rs0 = {p.rscale, p.rscale, p.rscale, p.rscale}, rs1 = rs0;
+    if (p.res && p.rvec && fast) {
+      rs0 *= *reinterpret_cast<const floatx4*>(p.rvec + nn);
+      rs1 *= *reinterpret_cast<const floatx4*>(p.rvec + nn + 4);
+    }
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+      floatx16 v = acc[im][jn];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bia;
+      if constexpr (GELU) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = v[e] * cs_;
+      // (the same wave wrote and reads T: LDS operations of one wave complete in order)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 16 + erow;
+        const int m = m0 + wrow + im * 32 + row;
+        if (m >= p.M) continue;
+        const float* tp = T + row * 36 + ecol;
+        if (fast) {
+          floatx4 o0 = *reinterpret_cast<const floatx4*>(tp), o1 = *reinterpret_cast<const floatx4*>(tp + 4);
+          if (p.res) {
+            const float* rp = p.res + (size_t)m * p.ldr + nn;
+            o0 += *reinterpret_cast<const floatx4*>(rp) * rs0;
+            o1 += *reinterpret_cast<const floatx4*>(rp + 4) * rs1;
+          }
+          if (p.out) {
+            float* op = p.out + (size_t)m * p.ldo + nn;
+            *reinterpret_cast<floatx4*>(op) = o0;
+            *reinterpret_cast<floatx4*>(op + 4) = o1;
+          }
+          if (p.o_hi) {
+            unsigned hh[4], ll[4];
+            split2(o0[0], o0[1], hh[0], ll[0]);
+            split2(o0[2], o0[3], hh[1], ll[1]);
+            split2(o1[0], o1[1], hh[2], ll[2]);
+            split2(o1[2], o1[3], hh[3], ll[3]);
+            const uintx4 hi4 = {hh[0], hh[1], hh[2], hh[3]}, lo4 = {ll[0], ll[1], ll[2], ll[3]};
+            *reinterpret_cast<uintx4*>(p.o_hi + (size_t)m * ldp + nn) = hi4;
+            *reinterpret_cast<uintx4*>(p.o_lo + (size_t)m * ldp + nn) = lo4;
+          }
+        } else {
+          // edge / unaligned columns: one pair at a time (rare: N % 8 != 0 tails, odd strides)
+#pragma nounroll
+          for (int c = 0; c < 8; c += 2) {
+            float x[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const int n = nn + c + d;
+              float o = 0.f;
+              if (n < p.N) {
+                o = tp[c + d];
+                if (p.res) o += p.res[(size_t)m * p.ldr + n] * (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
+                if (p.out) p.out[(size_t)m * p.ldo + n] = o;
+              }
+              x[d] = o;
+            }
+            if (p.o_hi && nn + c < ldp) {   // ldp is even: pairs are whole; columns >= N are written as zeros
+              unsigned hh, ll;
+              split2(x[0], x[1], hh, ll);
+              *reinterpret_cast<unsigned*>(p.o_hi + (size_t)m * ldp + nn + c) = hh;
+              *reinterpret_cast<unsigned*>(p.o_lo + (size_t)m * ldp + nn + c) = ll;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int STAGES, bool GELU, int SCHED>
+int launch_planes3(const PlaneArgs& a, hipStream_t st) {
+  constexpr int STAGE = 2 * (BM + BN) * 64;
+  static_assert(STAGES * STAGE >= (BM / 32) * 32 * 36 * 4, "epilogue scratch");
+  static_assert(STAGES * STAGE <= 160 * 1024, "LDS");
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * STAGE) != hipSuccess)
+      return FFSR_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>), dim3(tiles), dim3(BM * 2), STAGES * STAGE, st, a);
+  return ffsr_launch_status();
+}
+
+int g_planes_sched = 1;   // FFSR_PLANES_SCHED (diagnostic): 0 = burst issue, 1 = interleaved issue
+
+template <int BM, int BN, int STAGES, bool GELU>
+int launch_planes2(const PlaneArgs& a, hipStream_t st) {
+  return g_planes_sched ? launch_planes3<BM, BN, STAGES, GELU, 1>(a, st) : launch_planes3<BM, BN, STAGES, GELU, 0>(a, st);
+}
+
+template <int BM, int BN, int STAGES>
+int launch_planes(PlaneArgs& a, hipStream_t st) {
+  if (a.act == FFSR_ACT_GELU) return launch_planes2<BM, BN, STAGES, true>(a, st);
+  if (a.act == FFSR_ACT_NONE) a.slope = 1.f;
+  else if (a.act == FFSR_ACT_RELU) a.slope = 0.f;
+  else if (a.act != FFSR_ACT_LRELU) return FFSR_EINVAL;   // sigmoid / SiLU epilogues stay on ffsr_conv2d_bf16x3
+  return launch_planes2<BM, BN, STAGES, false>(a, st);
+}
+
+// fp32 [M, C] (row stride ldx) -> bf16 hi / lo planes [M, ldp] (columns C..ldp-1 zero).  One thread = 8 columns.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ hi,
+                                                           unsigned short* __restrict__ lo, int ldp, long long M, int C) {
+  const int groups = ldp >> 3;
+  const long long total = M * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / groups;
+    const int c0 = (int)(i - m * groups) * 8;
+    const float* xp = x + m * ldx + c0;
+    float v[8];
+    if (c0 + 8 <= C && (ldx & 3) == 0) {
+      const floatx4 a = *reinterpret_cast<const floatx4*>(xp), b = *reinterpret_cast<const floatx4*>(xp + 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { v[c] = a[c]; v[4 + c] = b[c]; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = c0 + c < C ? xp[c] : 0.f;
+    }
+    uintx4 h4, l4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned hh, ll;
+      split2(v[2 * c], v[2 * c + 1], hh, ll);
+      h4[c] = hh;
+      l4[c] = ll;
+    }
+    *reinterpret_cast<uintx4*>(hi + m * ldp + c0) = h4;
+    *reinterpret_cast<uintx4*>(lo + m * ldp + c0) = l4;
+  }
+}
+
+}  // namespace
+
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, const void* wgt_hi, const void* wgt_lo,
+                                  int n_rows_padded, const void* zeros, const float* bias, float* out, const float* res,
+                                  const float* cvec, const float* rvec, void* out_hi, void* out_lo, int ldp, int B, int H,
+                                  int W, int N, int ldo, int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act,
+                                  float slope, float cscale, float rscale, int bm, int bn, int stages, void* stream) {
+  FFSR_CHECK(a_hi && a_lo && wgt_hi && wgt_lo && zeros && (out || (out_hi && out_lo)));
+  FFSR_CHECK(B > 0 && H > 0 && W > 0 && N > 0 && KH > 0 && KW > 0 && KH * KW <= 32 && stride > 0);
+  FFSR_CHECK(Cp > 0 && (Cp & 31) == 0);
+  FFSR_CHECK(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)a_lo & 15) == 0 && ((uintptr_t)wgt_hi & 15) == 0 &&
+             ((uintptr_t)wgt_lo & 15) == 0 && ((uintptr_t)zeros & 15) == 0);
+  FFSR_CHECK(bn == 64 || bn == 128 || bn == 192 || bn == 256);
+  FFSR_CHECK(bm == 0 || bm == 128 || bm == 256);
+  FFSR_CHECK(n_rows_padded % bn == 0 && n_rows_padded >= N);
+  FFSR_CHECK(!out || (ldo >= N));
+  FFSR_CHECK(!res || ldr >= N);
+  FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= N && ldp < N + 32 && ((uintptr_t)out_hi & 15) == 0 &&
+                         ((uintptr_t)out_lo & 15) == 0));
+  PlaneArgs a;
+  a.a_hi = (const unsigned short*)a_hi; a.a_lo = (const unsigned short*)a_lo;
+  a.w_hi = (const unsigned short*)wgt_hi; a.w_lo = (const unsigned short*)wgt_lo; a.zeros = (const unsigned short*)zeros;
+  a.bias = bias; a.out = out; a.res = res; a.cvec = cvec; a.rvec = rvec;
+  a.o_hi = (unsigned short*)out_hi; a.o_lo = (unsigned short*)out_lo;
+  a.B = B; a.H = H; a.W = W; a.Cp = Cp; a.N = N;
+  a.Ho = (H + 2 * pad_h - KH) / stride + 1;
+  a.Wo = (W + 2 * pad_w - KW) / stride + 1;
+  FFSR_CHECK(a.Ho > 0 && a.Wo > 0);
+  a.ldo = ldo; a.ldr = ldr; a.ldp = ldp; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.act = act; a.slope = slope; a.cscale = cscale; a.rscale = rscale;
+  const long long M = (long long)B * a.Ho * a.Wo;
+  FFSR_CHECK(M < (1ll << 31));
+  FFSR_CHECK((long long)B * H * W * Cp * 2 < (1ll << 32));                       // 32-bit byte offsets into the A planes
+  FFSR_CHECK((long long)n_rows_padded * KH * KW * Cp * 2 < (1ll << 32));         // ... and into the weight planes
+  a.M = (int)M;
+  a.nk = KH * KW * (Cp / 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (bm == 0) bm = 128;
+  if (stages == 0) stages = 2;
+  if (stages >= 10) { g_planes_sched = 0; stages -= 10; } else g_planes_sched = 1;   // stages + 10: burst-issue variant (diagnostic)
+  switch ((bm / 128) * 10000 + bn * 10 + stages) {
+    case 10642: return launch_planes<128, 64, 2>(a, st);
+    case 10643: return launch_planes<128, 64, 3>(a, st);
+    case 11282: return launch_planes<128, 128, 2>(a, st);
+    case 11283: return launch_planes<128, 128, 3>(a, st);
+    case 11922: return launch_planes<128, 192, 2>(a, st);
+    case 21282: return launch_planes<256, 128, 2>(a, st);
+    case 21283: return launch_planes<256, 128, 3>(a, st);
+    case 21922: return launch_planes<256, 192, 2>(a, st);
+    case 22562: return launch_planes<256, 256, 2>(a, st);
+    default: return FFSR_EINVAL;
+  }
+}
+
+extern "C" int ffsr_split_planes(const float* x, int ldx, void* hi, void* lo, int ldp, long long M, int C, void* stream) {
+  FFSR_CHECK(x && hi && lo && M > 0 && C > 0 && (ldp & 31) == 0 && ldp >= C && ldx >= C);
+  FFSR_CHECK(((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0 && ((uintptr_t)x & 15) == 0);
+  const long long total = M * (ldp >> 3);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)hi,
+                     (unsigned short*)lo, ldp, M, C);
+  return ffsr_launch_status();
+}

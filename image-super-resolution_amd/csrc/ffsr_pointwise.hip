@@ -63,6 +63,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// Vectorised form (C % 4 == 0, 16-byte aligned rows): HALF a wave per row, 8 channels per lane and pass (two 16-byte
+// loads), NPASS passes cover C <= 256 * NPASS.  Outputs: fp32 `out` (optional) and / or the bf16 hi / lo planes of the
+// result (optional; [M, ldp], ldp % 32 == 0, columns C..ldp-1 written as zeros) for ffsr_conv2d_planes.
+template <int NPASS>
+__global__ __launch_bounds__(256) void layernorm_v8_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                           const float* __restrict__ b, float eps, float* __restrict__ out,
+                                                           int ldo, unsigned short* __restrict__ ohi,
+                                                           unsigned short* __restrict__ olo, int ldp,
+                                                           const float* __restrict__ r1, int ldr1,
+                                                           const float* __restrict__ r2, int ldr2, int M, int C) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
+  if (row >= M) return;     // whole half-waves leave together: the 32-lane shuffles below stay inside a half
+  const float* xr = x + (size_t)row * ldx;
+  floatx4 v[NPASS][2];
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = (p * 32 + l) * 8 + 4 * hh;
+      v[p][hh] = c < C ? *reinterpret_cast<const floatx4*>(xr + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+      s += (v[p][hh][0] + v[p][hh][1]) + (v[p][hh][2] + v[p][hh][3]);
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = (p * 32 + l) * 8 + 4 * hh;
+      if (c < C) {
+        const floatx4 d = v[p][hh] - mean;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int c0 = (p * 32 + l) * 8;
+    float y[8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = c0 + 4 * hh;
+      floatx4 t = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        t = (v[p][hh] - mean) * rstd * *reinterpret_cast<const floatx4*>(g + c) + *reinterpret_cast<const floatx4*>(b + c);
+        if (r1) t += *reinterpret_cast<const floatx4*>(r1 + (size_t)row * ldr1 + c);
+        if (r2) t += *reinterpret_cast<const floatx4*>(r2 + (size_t)row * ldr2 + c);
+        if (out) *reinterpret_cast<floatx4*>(out + (size_t)row * ldo + c) = t;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[4 * hh + e] = t[e];
+    }
+    if (ohi && c0 < ldp) ffsr_store_planes8(ohi + (size_t)row * ldp + c0, olo + (size_t)row * ldp + c0, y);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- elementwise
 // out = clamp( act(x * pre) * alpha * cscale[n] + beta + cbias[n] )
 template <int V>
@@ -435,13 +497,40 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 #define ST ((hipStream_t)stream)
 
+extern "C" int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                                         float* out, int ldo, void* out_hi, void* out_lo, int ldp, const float* res1,
+                                         int ldr1, const float* res2, int ldr2, int M, int C, void* stream) {
+  FFSR_CHECK(x && gamma && beta && (out || (out_hi && out_lo)) && M > 0 && C > 0 && C <= 1024 && ldx >= C);
+  FFSR_CHECK(!out || ldo >= C);
+  FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= C && ldp < C + 32 && al16(out_hi) && al16(out_lo)));
+  const bool v8 = (C % 4 == 0) && (ldx % 4 == 0) && al16(x) && al16(gamma) && al16(beta) && (!out || (ldo % 4 == 0 && al16(out))) &&
+                  (!res1 || (ldr1 % 4 == 0 && al16(res1))) && (!res2 || (ldr2 % 4 == 0 && al16(res2)));
+  if (!v8) {
+    FFSR_CHECK(out && !out_hi);   // the scalar fallback writes fp32 only
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, ldx, gamma, beta, eps, out, ldo, res1,
+                       ldr1, res2, ldr2, M, C);
+    return ffsr_launch_status();
+  }
+  unsigned short* oh = (unsigned short*)out_hi;
+  unsigned short* ol = (unsigned short*)out_lo;
+  const dim3 grid((M + 7) / 8), block(256);
+#define FFSR_LN(NP)                                                                                                      \
+  hipLaunchKernelGGL(layernorm_v8_kernel<NP>, grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1, \
+                     ldr1, res2, ldr2, M, C)
+  if (C <= 256) FFSR_LN(1);
+  else if (C <= 512) FFSR_LN(2);
+  else if (C <= 768) FFSR_LN(3);
+  else FFSR_LN(4);
+#undef FFSR_LN
+  return ffsr_launch_status();
+}
+
 extern "C" int ffsr_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out,
                                   int ldo, const float* res1, int ldr1, const float* res2, int ldr2, int M, int C,
                                   void* stream) {
-  FFSR_CHECK(x && gamma && beta && out && M > 0 && C > 0 && C <= 1024 && ldx >= C && ldo >= C);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, ldx, gamma, beta, eps, out, ldo, res1, ldr1,
-                     res2, ldr2, M, C);
-  return ffsr_launch_status();
+  FFSR_CHECK(out);
+  return ffsr_layernorm_planes_f32(x, ldx, gamma, beta, eps, out, ldo, nullptr, nullptr, 0, res1, ldr1, res2, ldr2, M, C,
+                                   stream);
 }
 
 extern "C" int ffsr_unary_f32(const float* x, int ldx, float* out, int ldo, long long M, int C, int act, float slope,

@@ -96,6 +96,57 @@ def rows(t: torch.Tensor) -> int:
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+# ---------------------------------------------------------------------------------------------- split planes
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+class Planes:
+    """A feature map stored PRE-SPLIT for the GEMM: bf16 hi / lo planes [2, B*H*W, Cp] (Cp = C rounded up to 32, pad
+    channels zero) -- the same bytes as fp32, consumed by ffsr_conv2d_planes without any conversion work."""
+
+    def __init__(self, B, H, W, C, device, buf=None):
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.Cp = pad32(C)
+        self.buf = buf if buf is not None else torch.empty(2, B * H * W, self.Cp, device=device, dtype=torch.bfloat16)
+
+    @property
+    def shape(self):
+        return (self.B, self.H, self.W, self.C)
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+    @property
+    def hi(self):
+        return self.buf[0]
+
+    @property
+    def lo(self):
+        return self.buf[1]
+
+    def reshape_map(self, B, H, W):
+        assert B * H * W == self.M
+        return Planes(B, H, W, self.C, self.buf.device, self.buf)
+
+    def to_f32(self) -> torch.Tensor:
+        """hi + lo as an fp32 map (tests / debugging only)."""
+        v = self.buf[0].float() + self.buf[1].float()
+        return v[:, :self.C].reshape(self.B, self.H, self.W, self.C)
+
+
+def split_planes(x: torch.Tensor, out: Optional[Planes] = None) -> Planes:
+    """fp32 map / matrix -> Planes (one HBM pass)."""
+    if x.dim() == 2:
+        x = as_map(x)
+    B, H, W, C = x.shape
+    if out is None:
+        out = Planes(B, H, W, C, x.device)
+    hip.call("ffsr_split_planes", _ptr(x), ld(x), _ptr(out.hi), _ptr(out.lo), out.Cp, B * H * W, C, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- packed weights
 @dataclass
 class Conv:
@@ -111,6 +162,9 @@ class Conv:
     Cin_true: int = 0   # unpadded input channels (algorithmic flop accounting)
     whi: Optional[torch.Tensor] = None   # bf16 hi plane [Npad, Kpad] (split-bf16 path)
     wlo: Optional[torch.Tensor] = None   # bf16 lo plane
+    phi: Optional[torch.Tensor] = None   # bf16 hi plane [Npad768, taps * pad32(Cin)] (pre-split-input path)
+    plo: Optional[torch.Tensor] = None
+    Cp32: int = 0                        # channels per tap of phi / plo
 
 
 def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
@@ -134,8 +188,15 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=
     h = w2.to(torch.bfloat16)
     hi[:N, :w2.shape[1]] = h
     lo[:N, :w2.shape[1]] = (w2 - h.float()).to(torch.bfloat16)
+    # planes path: every tap padded to a multiple of 32 channels, rows padded to x768 (any column tile of 64/128/192/256)
+    C32, Np3 = pad32(Cin), (N + 767) // 768 * 768
+    w3 = torch.zeros(Np3, KH, KW, C32, dtype=torch.float32)
+    w3[:N, :, :, :Cin] = w.permute(0, 2, 3, 1)
+    w3 = w3.reshape(Np3, KH * KW * C32)
+    ph = w3.to(torch.bfloat16)
+    pl = (w3 - ph.float()).to(torch.bfloat16)
     return Conv(w2.to(device), None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride,
-                pad, Cin, hi.to(device), lo.to(device))
+                pad, Cin, hi.to(device), lo.to(device), ph.to(device), pl.to(device), C32)
 
 
 _ZEROS = {}
@@ -144,65 +205,107 @@ _ZEROS = {}
 def zero_page(device) -> torch.Tensor:
     key = str(device)
     if key not in _ZEROS:
-        _ZEROS[key] = torch.zeros(64, device=device)
+        _ZEROS[key] = torch.zeros(64, device=device)   # 256 B, 16-byte aligned
     return _ZEROS[key]
 
 
-def conv2d(x: torch.Tensor, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
+def planes_bn(N: int) -> int:
+    """Column tile of the planes GEMM: least padded N, the wider tile on ties."""
+    best = None
+    for bn in (192, 128, 64):
+        padded = (N + bn - 1) // bn * bn
+        if best is None or padded < best[0]:
+            best = (padded, bn)
+    return best[1]
+
+
+PLANES_ACTS = (ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU)
+
+
+def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
            res: Optional[torch.Tensor] = None, cvec=None, rvec=None, cscale=1.0, rscale=1.0, shuffle=0,
-           akscale: Optional[torch.Tensor] = None, tile_hint=0) -> torch.Tensor:
-    """x [B,H,W,>=Cin] -> [B,Ho,Wo,N] (or [B,2Ho,2Wo,N/4] with shuffle=2)."""
+           akscale: Optional[torch.Tensor] = None, tile_hint=0, out_planes=None, want_f32=True, bm=0, bn=0, stages=0):
+    """x [B,H,W,>=Cin] fp32 map or Planes -> [B,Ho,Wo,N] (or [B,2Ho,2Wo,N/4] with shuffle=2).
+    out_planes: True / a Planes object -> also emit the result as bf16 hi / lo planes (returned as (out, planes), or
+    only the planes when want_f32 is False)."""
     B, H, W, _ = x.shape
-    ldi = ld(x)
-    assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"
     Ho = (H + 2 * cv.pad - cv.KH) // cv.stride + 1
     Wo = (W + 2 * cv.pad - cv.KW) // cv.stride + 1
     if shuffle:
         oshape = (B, 2 * Ho, 2 * Wo, cv.N // 4)
     else:
         oshape = (B, Ho, Wo, cv.N)
-    if out is None:
-        out = new_map(*oshape, x.device)
-    assert tuple(out.shape) == oshape, f"{tuple(out.shape)} != {oshape}"
+    is_planes = isinstance(x, Planes)
+    if out_planes is True:
+        out_planes = Planes(B, Ho, Wo, cv.N, x.buf.device if is_planes else x.device)
+    if out_planes is not None and not is_planes:
+        raise ValueError("planes output needs a Planes input (split_planes the input first)")
+    dev_ = x.buf.device if is_planes else x.device
+    if out is None and (want_f32 or out_planes is None):
+        out = new_map(*oshape, dev_)
+    if out is not None:
+        assert tuple(out.shape) == oshape, f"{tuple(out.shape)} != {oshape}"
     ldr = 0
     if res is not None:
         assert tuple(res.shape) == oshape
         ldr = ld(res)
-    akrows = 0
-    if akscale is not None:
-        assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
-        akrows = H * W
-    if tile_hint == 0 and GEMM_MODE == "bf16x3" and B * Ho * Wo > 64 * 24 and cv.KH * cv.KW <= 32:
-        tile_hint = 64 if cv.N <= 64 or BN128_MIN_N > cv.N else 128
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if tile_hint in (64, 128):
-        hip.call("ffsr_conv2d_bf16x3", _ptr(x), _ptr(cv.whi), _ptr(cv.wlo), cv.whi.shape[1], cv.whi.shape[0],
-                 _ptr(zero_page(x.device)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec), _ptr(akscale),
-                 B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope),
-                 float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+    if is_planes:
+        assert x.Cp == cv.Cp32 and x.C == cv.Cin_true, f"planes input {x.shape} (Cp {x.Cp}) vs conv Cin {cv.Cin_true}"
+        assert not shuffle and akscale is None and act in PLANES_ACTS
+        if out_planes is not None:
+            assert out_planes.shape == oshape
+        hip.call("ffsr_conv2d_planes", _ptr(x.hi), _ptr(x.lo), x.Cp, _ptr(cv.phi), _ptr(cv.plo), cv.phi.shape[0],
+                 _ptr(zero_page(dev_)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
+                 None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
+                 0 if out_planes is None else out_planes.Cp, B, H, W, cv.N, 0 if out is None else ld(out), ldr, cv.KH,
+                 cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope), float(cscale), float(rscale),
+                 bm, bn or planes_bn(cv.N), stages, _stream())
     else:
-        hip.call("ffsr_conv2d_f32", _ptr(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
-                 _ptr(akscale), B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad,
-                 act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+        ldi = ld(x)
+        assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"
+        akrows = 0
+        if akscale is not None:
+            assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
+            akrows = H * W
+        if tile_hint == 0 and GEMM_MODE == "bf16x3" and B * Ho * Wo > 64 * 24 and cv.KH * cv.KW <= 32:
+            tile_hint = 64 if cv.N <= 64 or BN128_MIN_N > cv.N else 128
+        if tile_hint in (64, 128):
+            hip.call("ffsr_conv2d_bf16x3", _ptr(x), _ptr(cv.whi), _ptr(cv.wlo), cv.whi.shape[1], cv.whi.shape[0],
+                     _ptr(zero_page(x.device)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec), _ptr(akscale),
+                     B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope),
+                     float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
+        else:
+            hip.call("ffsr_conv2d_f32", _ptr(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
+                     _ptr(akscale), B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad,
+                     act, float(slope), float(cscale), float(rscale), shuffle, akrows, tile_hint, _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true,
                      (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH),
                      4.0 * (B * H * W * cv.Cin_true + cv.N * cv.KH * cv.KW * cv.Cin_true
                             + B * Ho * Wo * cv.N * (2 if res is not None else 1))))
+    if out_planes is not None:
+        return (out, out_planes) if out is not None else out_planes
     return out
 
 
-def linear(x2d: torch.Tensor, cv: Conv, **kw) -> torch.Tensor:
-    """x2d [M, K] -> [M, N]; keyword tensors (out / res) are [M, *] matrices too."""
+def linear(x2d, cv: Conv, **kw):
+    """x2d [M, K] matrix or Planes -> [M, N]; keyword tensors (out / res) are [M, *] matrices too."""
     for k in ("out", "res"):
         if kw.get(k) is not None:
             kw[k] = as_map(kw[k])
-    y = conv2d(as_map(x2d), cv, **kw)
-    return y.as_strided((y.shape[2], y.shape[3]), (ld(y), 1), y.storage_offset())
+    y = conv2d(x2d if isinstance(x2d, Planes) else as_map(x2d), cv, **kw)
+
+    def mat(t):
+        return t.as_strided((t.shape[2], t.shape[3]), (ld(t), 1), t.storage_offset())
+
+    if isinstance(y, tuple):
+        return mat(y[0]), y[1]
+    return y if isinstance(y, Planes) else mat(y)
 
 
 # ---------------------------------------------------------------------------------------------- row kernels
@@ -223,15 +326,25 @@ def _like(t: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     return new_map(t.shape[0], t.shape[1], t.shape[2], C or t.shape[3], t.device)
 
 
-def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None):
+def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None, out_planes=None, want_f32=True):
+    """out = LN(x) * gamma + beta (+ res1) (+ res2).  out_planes: True / a Planes -> also emit the result as bf16 hi / lo
+    planes for the planes GEMM (returns (out, planes), or only the planes when want_f32 is False)."""
     _, M, C, ldx = _mat(x)
-    if out is None:
+    if out_planes is True:
+        out_planes = Planes(1, 1, M, C, x.device) if x.dim() == 2 else Planes(x.shape[0], x.shape[1], x.shape[2], C, x.device)
+    if out is None and (want_f32 or out_planes is None):
         out = _like(x)
     r1 = _mat(res1) if res1 is not None else (None, 0, 0, 0)
     r2 = _mat(res2) if res2 is not None else (None, 0, 0, 0)
-    hip.call("ffsr_layernorm_f32", _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _mat(out)[3],
-             _ptr(r1[0]), r1[3], _ptr(r2[0]), r2[3], M, C, _stream())
-    return out
+    if out_planes is None:
+        hip.call("ffsr_layernorm_f32", _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _mat(out)[3],
+                 _ptr(r1[0]), r1[3], _ptr(r2[0]), r2[3], M, C, _stream())
+        return out
+    assert out_planes.M == M and out_planes.C == C
+    hip.call("ffsr_layernorm_planes_f32", _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(out),
+             0 if out is None else _mat(out)[3], _ptr(out_planes.hi), _ptr(out_planes.lo), out_planes.Cp, _ptr(r1[0]), r1[3],
+             _ptr(r2[0]), r2[3], M, C, _stream())
+    return (out, out_planes) if out is not None else out_planes
 
 
 def unary(x, act=ACT_NONE, slope=0.0, pre=1.0, alpha=1.0, beta=0.0, cscale=None, cbias=None, clamp=None, out=None):

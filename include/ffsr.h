@@ -52,11 +52,35 @@ int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, 
                        int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope, float cscale,
                        float rscale, int shuffle, int akrows, int bn, void* stream);
 
+/* The same split-bf16 operator with the A operand PRE-SPLIT in HBM: a_hi / a_lo are bf16 planes [B*H*W, Cp]
+ * (hi = bf16(x), lo = bf16(x - hi); Cp % 32 == 0, channels >= the true Cin are zero) -- the same bytes as fp32.  Both
+ * operands then go global -> LDS by LDS-DMA with no vector-ALU work in the main loop.  Weights: bf16 planes
+ * [n_rows_padded, KH*KW*Cp] (tap-major, Cp channels per tap, zero padded; n_rows_padded % bn == 0).  Outputs: fp32
+ * `out` (may be NULL) and / or bf16 planes out_hi / out_lo [M, ldp] (may be NULL; ldp = N rounded up to 32, columns
+ * >= N are written as zeros) for a following ffsr_conv2d_planes.  act: 0 none, 1 GELU, 2 ReLU, 3 LeakyReLU only.
+ * bm x bn = 128 / 256 rows x 64 / 128 / 192 / 256 columns tile (bm 0 = 128); stages = LDS pipeline depth (0 = default).  Replaces the same reference calls as
+ * ffsr_conv2d_f32 wherever the producer of the input can emit planes (LayerNorm, attention, gates, a previous GEMM). */
+int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, const void* wgt_hi, const void* wgt_lo,
+                       int n_rows_padded, const void* zeros, const float* bias, float* out, const float* res,
+                       const float* cvec, const float* rvec, void* out_hi, void* out_lo, int ldp, int B, int H, int W,
+                       int N, int ldo, int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                       float cscale, float rscale, int bm, int bn, int stages, void* stream);
+
+/* fp32 [M, C] (row stride ldx) -> bf16 hi / lo planes [M, ldp] (ldp % 32 == 0, columns C..ldp-1 zero). */
+int ffsr_split_planes(const float* x, int ldx, void* hi, void* lo, int ldp, long long M, int C, void* stream);
+
 /* out = LayerNorm_C(x) * gamma + beta (+ res1) (+ res2); biased variance, rows of C <= 1024.
  * Replaces nn.LayerNorm (drct_arch.py:385, grl mixed_attn_block_efficient.py:543-554 incl. the post-norm residual
  * sums, mambair_arch.py:417-419) and NAFNet's LayerNorm2d (nafnet_arch.py:26-44). */
 int ffsr_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out, int ldo,
                        const float* res1, int ldr1, const float* res2, int ldr2, int M, int C, void* stream);
+
+/* ffsr_layernorm_f32 that can also (or only) emit the result as bf16 hi / lo planes [M, ldp] (ldp = C rounded up to
+ * 32, pad columns zero) for ffsr_conv2d_planes: out may be NULL when out_hi / out_lo are given.  Plane output needs
+ * the vectorised path (C % 4 == 0, 16-byte aligned rows). */
+int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out,
+                              int ldo, void* out_hi, void* out_lo, int ldp, const float* res1, int ldr1,
+                              const float* res2, int ldr2, int M, int C, void* stream);
 
 /* out = clamp(act(x * pre) * alpha * cscale[n] + beta + cbias[n], lo, hi) (cscale, cbias [C] optional; clamp only if
  * do_clamp).  Covers eval-mode BatchNorm (large_kernel_attention.py:143), mean shifts, clamps, activations. */

@@ -1,0 +1,124 @@
+"""GPU: the pre-split-input GEMM (ffsr_conv2d_planes) and the plane producers against plain PyTorch fp32 and against
+the fp32-input split-bf16 kernel (same arithmetic, different staging)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def E(pkg):
+    import importlib
+    return importlib.import_module("image-super-resolution_amd.engine")
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    import importlib
+    return importlib.import_module("image-super-resolution_amd.ops")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(got, want, tol, what=""):
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= tol * max(1.0, ref), f"{what}: max err {err:.3e} (ref max {ref:.3e}, tol {tol})"
+
+
+ACT = {0: lambda v: v, 1: F.gelu, 2: F.relu, 3: lambda v: F.leaky_relu(v, 0.2)}
+
+
+def test_split_planes_roundtrip(ops, E):
+    x = rnd(2, 45, 7, 9, seed=1)
+    xm = E.nchw_to_map(x, DEV)
+    pl = ops.split_planes(xm)
+    assert pl.Cp == 64 and pl.buf.shape == (2, 2 * 7 * 9, 64)
+    back = pl.to_f32().permute(0, 3, 1, 2).cpu()
+    close(back, x, 2.0 ** -16, "hi + lo")                                  # 16 mantissa bits survive the split
+    assert (pl.buf[:, :, 45:] == 0).all()                                  # pad channels are zero
+    h = x.to(torch.bfloat16)                                               # bit-exact definition of the planes
+    assert torch.equal(pl.hi[:, :45].reshape(2, 7, 9, 45).cpu(), h.permute(0, 2, 3, 1))
+    assert torch.equal(pl.lo[:, :45].reshape(2, 7, 9, 45).cpu(), (x - h.float()).to(torch.bfloat16).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N,k,stride,act,bm,bn,stages", [
+    (1, 25, 40, 180, 360, 1, 1, 1, 0, 0, 0), (1, 25, 40, 180, 360, 1, 1, 0, 128, 64, 2), (1, 25, 40, 180, 360, 1, 1, 0, 128, 64, 3),
+    (1, 25, 40, 180, 360, 1, 1, 3, 128, 128, 2), (1, 25, 40, 180, 360, 1, 1, 2, 128, 128, 3),
+    (1, 25, 40, 180, 360, 1, 1, 0, 128, 192, 2), (1, 25, 40, 180, 360, 1, 1, 1, 256, 128, 2),
+    (1, 25, 40, 180, 360, 1, 1, 0, 256, 128, 3), (1, 25, 40, 180, 360, 1, 1, 3, 256, 192, 2),
+    (1, 25, 40, 180, 360, 1, 1, 0, 256, 256, 2), (2, 20, 24, 60, 180, 3, 1, 1, 256, 192, 2),
+    (2, 20, 24, 60, 180, 3, 1, 1, 0, 0, 0), (1, 18, 22, 180, 45, 3, 1, 0, 0, 0, 0), (1, 12, 12, 64, 128, 2, 2, 0, 0, 0, 0),
+    (1, 33, 35, 128, 128, 3, 1, 1, 0, 0, 0), (1, 33, 35, 128, 128, 3, 1, 1, 256, 128, 3), (1, 16, 16, 308, 180, 1, 1, 3, 0, 0, 0),
+    (3, 1, 1, 180, 10, 1, 1, 2, 0, 0, 0), (1, 40, 52, 360, 176, 1, 1, 0, 0, 0, 0), (1, 40, 52, 64, 512, 1, 1, 0, 256, 256, 2),
+])
+def test_conv2d_planes_vs_torch_and_vs_f32_input_kernel(ops, E, B, H, W, Cin, N, k, stride, act, bm, bn, stages):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(N, Cin, k, k, seed=2, scale=1 / math.sqrt(Cin * k * k)), rnd(N, seed=3)
+    pad = 0 if k == 2 else k // 2
+    want = ACT[act](F.conv2d(x, w, b, stride=stride, padding=pad))
+    cv = ops.pack_conv(w, b, DEV, stride=stride, pad=pad)
+    xm = E.nchw_to_map(x, DEV)
+    got = ops.conv2d(ops.split_planes(xm), cv, act=act, slope=0.2, bm=bm, bn=bn, stages=stages)
+    close(E.map_to_nchw(got), want, 2e-4, "planes vs torch")
+    if B * H * W > 64 * 24:
+        same = ops.conv2d(ops.widen(xm, cv.Cin), cv, act=act, slope=0.2, tile_hint=64)   # fp32-in split-bf16 kernel
+        close(got, same, 2e-6, "planes vs fp32-input kernel")
+
+
+def test_conv2d_planes_epilogue_and_plane_output(ops, E):
+    B, H, W, C, N = 2, 10, 13, 64, 180
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, 1, 1, seed=2, scale=0.1), rnd(N, seed=3)
+    res, cvec, rvec = rnd(B, N, H, W, seed=4), rnd(N, seed=5), rnd(N, seed=6)
+    want = res * rvec[None, :, None, None] * 0.5 + F.conv2d(x, w, b) * cvec[None, :, None, None] * 2.0
+    cv = ops.pack_conv(w, b, DEV)
+    xp = ops.split_planes(E.nchw_to_map(x, DEV))
+    out, pl = ops.conv2d(xp, cv, res=E.nchw_to_map(res, DEV), cvec=cvec.to(DEV), rvec=rvec.to(DEV), cscale=2.0, rscale=0.5,
+                         out_planes=True)
+    close(E.map_to_nchw(out), want, 2e-4, "epilogue")
+    assert pl.Cp == 192 and (pl.buf[:, :, N:] == 0).all()
+    assert torch.equal(pl.buf, ops.split_planes(out).buf)                  # the plane output is exactly split(out)
+    only = ops.conv2d(xp, cv, res=E.nchw_to_map(res, DEV), cvec=cvec.to(DEV), rvec=rvec.to(DEV), cscale=2.0, rscale=0.5,
+                      out_planes=True, want_f32=False)
+    assert torch.equal(only.buf, pl.buf)
+    # output written into a channel slice of a wider buffer (row stride > N, N % 8 != 0 -> edge path)
+    wide = torch.full((B, H, W, 64), 7.0, device=DEV)
+    cv2 = ops.pack_conv(rnd(45, C, 1, 1, seed=8, scale=0.1), rnd(45, seed=9), DEV)
+    sl = wide[..., 8:8 + 45]
+    ops.conv2d(xp, cv2, out=sl)
+    close(sl.permute(0, 3, 1, 2).cpu(), F.conv2d(x, rnd(45, C, 1, 1, seed=8, scale=0.1), rnd(45, seed=9)), 2e-4, "slice")
+    assert (wide[..., :8] == 7).all() and (wide[..., 53:] == 7).all()
+
+
+def test_chained_planes_gemms_match_f32_chain(ops, E):
+    """fc1 (GELU, planes out) -> fc2 (+ residual): the chain never materialises fp32 between the GEMMs."""
+    M, C = 3000, 180
+    x = rnd(M, C, seed=1)
+    w1, b1, w2, b2 = rnd(2 * C, C, seed=2, scale=0.07), rnd(2 * C, seed=3), rnd(C, 2 * C, seed=4, scale=0.05), rnd(C, seed=5)
+    want = x + F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2)
+    f1, f2 = ops.pack_conv(w1, b1, DEV), ops.pack_conv(w2, b2, DEV)
+    xd = x.to(DEV)
+    h = ops.linear(ops.split_planes(xd), f1, act=1, out_planes=True, want_f32=False)
+    got = ops.linear(h, f2, res=xd)
+    close(got.cpu(), want, 2e-4, "mlp chain")
+
+
+@pytest.mark.parametrize("M,C,ldx", [(1000, 180, 308), (37, 64, 64), (513, 308, 308), (100, 1024, 1024), (64, 360, 720)])
+def test_layernorm_plane_output(ops, M, C, ldx):
+    """LayerNorm (+ residuals) emitting fp32 and planes: the planes are exactly split(fp32 result)."""
+    xw = rnd(M, ldx, seed=1)
+    x = xw.to(DEV)[:, :C]
+    g, b, r1, r2 = rnd(C, seed=2), rnd(C, seed=3), rnd(M, C, seed=4), rnd(M, C, seed=5)
+    want = F.layer_norm(xw[:, :C], (C,), g, b, 1e-5) + r1 + r2
+    out, pl = ops.layernorm(x, g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV), out_planes=True)
+    close(out.cpu(), want, 1e-5, "layernorm")
+    assert torch.equal(pl.buf, ops.split_planes(out).buf)
+    only = ops.layernorm(x, g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV), out_planes=True, want_f32=False)
+    assert torch.equal(only.buf, pl.buf)
+    plain = ops.layernorm(x, g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV))
+    assert torch.equal(plain, out)
