@@ -66,8 +66,11 @@ class CAB:
                                 cin_pad=ops.pad4(sq))
 
     def __call__(self, x):
-        c1 = ops.conv2d(x, self.c0, act=ACT_GELU)
-        c2 = ops.conv2d(ops.widen(c1, self.c2.Cin), self.c2)
+        if isinstance(x, ops.Planes):      # conv -> GELU -> conv without an fp32 round trip
+            c2 = ops.conv2d(ops.conv2d(x, self.c0, act=ACT_GELU, out_planes=True, want_f32=False), self.c2)
+        else:
+            c1 = ops.conv2d(x, self.c0, act=ACT_GELU)
+            c2 = ops.conv2d(ops.widen(c1, self.c2.Cin), self.c2)
         pooled = ops.colmean(c2)                                           # [B, C]
         s = ops.linear(pooled, self.a1, act=ACT_RELU)                      # [B, C/r] (zero padded to x4)
         s = s.as_strided((s.shape[0], self.a3.Cin), (s.stride(0), 1), s.storage_offset())

@@ -218,6 +218,74 @@ __global__ __launch_bounds__(256) void mamba_norm_gate_kernel(const float* __res
   }
 }
 
+// Vectorised form (C % 4 == 0, 16-byte aligned rows): half a wave per row, 8 channels per lane and pass; fp32 output
+// and / or the bf16 hi / lo planes of the result ([M, ldp], pad columns zero) for ffsr_conv2d_planes (out_proj).
+template <int NPASS>
+__global__ __launch_bounds__(256) void mamba_norm_gate_v8_kernel(const float* __restrict__ y, size_t ystride, int ldy,
+                                                                 const float* __restrict__ z, int ldz,
+                                                                 const float* __restrict__ g, const float* __restrict__ be,
+                                                                 float eps, float* __restrict__ out, int ldo,
+                                                                 unsigned short* __restrict__ ohi,
+                                                                 unsigned short* __restrict__ olo, int ldp, int M, int C) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
+  if (row >= M) return;
+  floatx4 v[NPASS][2];
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = (p * 32 + l) * 8 + 4 * hh;
+      floatx4 t = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        const float* p0 = y + (size_t)row * ldy + c;
+        // y1+y2+y3+y4 in the order of mambair_arch.py:381
+        t = ((*reinterpret_cast<const floatx4*>(p0) + *reinterpret_cast<const floatx4*>(p0 + 2 * ystride)) +
+             *reinterpret_cast<const floatx4*>(p0 + ystride)) + *reinterpret_cast<const floatx4*>(p0 + 3 * ystride);
+      }
+      v[p][hh] = t;
+      s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = (p * 32 + l) * 8 + 4 * hh;
+      if (c < C) {
+        const floatx4 d = v[p][hh] - mean;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int c0 = (p * 32 + l) * 8;
+    float r[8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = c0 + 4 * hh;
+      floatx4 t = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        const floatx4 zz = *reinterpret_cast<const floatx4*>(z + (size_t)row * ldz + c);
+        const floatx4 yn = (v[p][hh] - mean) * rstd * *reinterpret_cast<const floatx4*>(g + c) + *reinterpret_cast<const floatx4*>(be + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = yn[e] * (zz[e] / (1.0f + expf(-zz[e])));
+        if (out) *reinterpret_cast<floatx4*>(out + (size_t)row * ldo + c) = t;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[4 * hh + e] = t[e];
+    }
+    if (ohi && c0 < ldp) ffsr_store_planes8(ohi + (size_t)row * ldp + c0, olo + (size_t)row * ldp + c0, r);
+  }
+}
+
 template <int R>
 int run_scan(const ScanArgs& a, hipStream_t st) {
   dim3 grid((a.Dm + 63) / 64, a.nchunk, 4 * a.B);
@@ -251,11 +319,35 @@ extern "C" int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xd
   }
 }
 
+extern "C" int ffsr_mamba_norm_gate_planes_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
+                                               const float* gamma, const float* beta, float eps, float* out, int ldo,
+                                               void* out_hi, void* out_lo, int ldp, int M, int C, void* stream) {
+  FFSR_CHECK(y && z && gamma && beta && (out || (out_hi && out_lo)) && M > 0 && C > 0 && C <= 512);
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= C && ldp < C + 32 && al(out_hi) && al(out_lo)));
+  const bool v8 = (C % 4 == 0) && (ldy % 4 == 0) && (ystride % 4 == 0) && (ldz % 4 == 0) && al(y) && al(z) && al(gamma) &&
+                  al(beta) && (!out || (ldo % 4 == 0 && al(out)));
+  hipStream_t st = (hipStream_t)stream;
+  if (!v8) {
+    FFSR_CHECK(out && !out_hi);
+    hipLaunchKernelGGL(mamba_norm_gate_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz, gamma,
+                       beta, eps, out, ldo, M, C);
+    return ffsr_launch_status();
+  }
+  unsigned short* oh = (unsigned short*)out_hi;
+  unsigned short* ol = (unsigned short*)out_lo;
+  if (C <= 256)
+    hipLaunchKernelGGL(mamba_norm_gate_v8_kernel<1>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
+                       gamma, beta, eps, out, ldo, oh, ol, ldp, M, C);
+  else
+    hipLaunchKernelGGL(mamba_norm_gate_v8_kernel<2>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
+                       gamma, beta, eps, out, ldo, oh, ol, ldp, M, C);
+  return ffsr_launch_status();
+}
+
 extern "C" int ffsr_mamba_norm_gate_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
                                         const float* gamma, const float* beta, float eps, float* out, int ldo, int M, int C,
                                         void* stream) {
-  FFSR_CHECK(y && z && gamma && beta && out && M > 0 && C > 0 && C <= 512);
-  hipLaunchKernelGGL(mamba_norm_gate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, (size_t)ystride, ldy, z,
-                     ldz, gamma, beta, eps, out, ldo, M, C);
-  return ffsr_launch_status();
+  FFSR_CHECK(out);
+  return ffsr_mamba_norm_gate_planes_f32(y, ystride, ldy, z, ldz, gamma, beta, eps, out, ldo, nullptr, nullptr, 0, M, C, stream);
 }

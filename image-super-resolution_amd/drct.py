@@ -26,11 +26,16 @@ class _Swin:
 
     def __call__(self, x, B, H, W):
         """x [P, dim] (row stride may be wider) -> [P, dim]"""
-        n = ops.layernorm(x, *self.n1)
+        pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"   # LN / fc1 results go to the GEMMs as bf16 hi/lo planes
+        n = ops.layernorm(x, *self.n1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.n1)
         qkv = ops.linear(n, self.qkv)
         a = ops.window_attn(qkv, self.bias, B, H, W, self.dim, self.heads, self.ws, self.shift, self.scale)
         y = ops.linear(a, self.proj, res=x)
-        h = ops.linear(ops.layernorm(y, *self.n2), self.fc1, act=ACT_GELU)
+        if not pl:
+            h = ops.linear(ops.layernorm(y, *self.n2), self.fc1, act=ACT_GELU)
+            return ops.linear(h, self.fc2, res=y)
+        h = ops.linear(ops.layernorm(y, *self.n2, out_planes=True, want_f32=False), self.fc1, act=ACT_GELU,
+                       out_planes=True, want_f32=False)
         return ops.linear(h, self.fc2, res=y)
 
 
@@ -75,5 +80,4 @@ class DRCT:
                 else:
                     ops.linear(y, adj, cscale=0.2, res=buf[:, :E], out=cat[1 - cur][:, :E])     # x5 * 0.2 + x
             cur = 1 - cur
-        t = ops.layernorm(cat[cur][:, :E], *self.norm)
-        return self.tail(to_map(t, B, H, W), x0)
+        return self.tail(ops.final_norm(cat[cur][:, :E], self.norm, B, H, W), x0)

@@ -285,9 +285,14 @@ class FusionNet:
         gates, diff = self.selector(routing)
         fused = torch.empty(B, Hh, Wh, 4, device=self.device)
         ops.fusion_route(enh, hier, routing, self.fw, gates, diff, fused)
-        r = fused
-        for cv in self.refine[:-1]:
-            r = ops.conv2d(r, cv, act=ACT_GELU)
+        if ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3":   # the whole 6-conv stack runs on bf16 hi/lo planes
+            r = ops.split_planes(fused[..., :3])
+            for cv in self.refine[:-1]:
+                r = ops.conv2d(r, cv, act=ACT_GELU, out_planes=True, want_f32=False)
+        else:
+            r = fused
+            for cv in self.refine[:-1]:
+                r = ops.conv2d(r, cv, act=ACT_GELU)
         refined = ops.conv2d(r, self.refine[-1], res=fused[..., :3], cscale=0.1)
         out = ops.new_map(B, Hh, Wh, 3, self.device)
         self.laplacian_refine(refined, lr, out)

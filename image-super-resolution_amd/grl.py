@@ -68,11 +68,13 @@ class _Block:
         self.fc1 = ops.pack_conv(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], device)
         self.fc2 = ops.pack_conv(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], device)
 
-    def __call__(self, x, B, H, W):
-        """x [P, dim] contiguous tokens -> [P, dim]"""
+    def __call__(self, x, B, H, W, xp=None):
+        """x [P, dim] contiguous tokens (xp: the same tensor as bf16 hi/lo planes, if the producer emitted them)
+        -> ([P, dim], planes of it or None)"""
         C, hd, heads = self.dim, self.hd, self.heads
+        pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"
         xm = to_map(x, B, H, W)
-        qkv = ops.linear(x, self.qkv)                                      # [P, 3C]: window half | stripe half
+        qkv = ops.linear(xp if xp is not None else x, self.qkv)            # [P, 3C]: window half | stripe half
         anchor = ops.conv2d(ops.avgpool2(xm), self.anchor)                # [B, H/2, W/2, C/2]
         cat = torch.empty(x.shape[0], C, device=x.device)
         ops.grl_window_attn(qkv, 0, self.bw, self.lw, cat, 0, B, H, W, heads, hd, self.shift)
@@ -80,9 +82,13 @@ class _Block:
         a = ops.linear(cat, self.proj)
         c2, att = self.cab(xm)
         base = ops.scale_add(xm, c2, bvec=att)                             # x + CAB(x)
-        y = ops.layernorm(a, *self.n1, res1=tokens(base))                  # + LN(attn(x))
-        m = ops.linear(ops.linear(y, self.fc1, act=ACT_GELU), self.fc2)
-        return ops.layernorm(m, *self.n2, res1=y)
+        if not pl:
+            y = ops.layernorm(a, *self.n1, res1=tokens(base))              # + LN(attn(x))
+            m = ops.linear(ops.linear(y, self.fc1, act=ACT_GELU), self.fc2)
+            return ops.layernorm(m, *self.n2, res1=y), None
+        y, yp = ops.layernorm(a, *self.n1, res1=tokens(base), out_planes=True)
+        m = ops.linear(ops.linear(yp, self.fc1, act=ACT_GELU, out_planes=True, want_f32=False), self.fc2)
+        return ops.layernorm(m, *self.n2, res1=y, out_planes=True)
 
 
 class GRL:
@@ -113,9 +119,9 @@ class GRL:
         x0 = ops.conv2d(self.tail.center(lr), self.conv_first)
         t = ops.layernorm(tokens(x0), *self.norm_start)
         for blocks, conv in self.stages:
-            r = t
+            r, rp = t, None
             for blk in blocks:
-                r = blk(r, B, H, W)
-            t = tokens(ops.conv2d(to_map(r, B, H, W), conv, res=to_map(t, B, H, W)))
-        t = ops.layernorm(t, *self.norm_end)
-        return self.tail(to_map(t, B, H, W), x0)
+                r, rp = blk(r, B, H, W, rp)
+            src = rp.reshape_map(B, H, W) if rp is not None else to_map(r, B, H, W)
+            t = tokens(ops.conv2d(src, conv, res=to_map(t, B, H, W)))
+        return self.tail(ops.final_norm(t, self.norm_end, B, H, W), x0)

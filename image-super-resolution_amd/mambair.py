@@ -39,14 +39,19 @@ class _VSS:
     def __call__(self, x, B, H, W):
         """x [P, C] tokens -> [P, C]"""
         Dm = self.Dm
-        xz = ops.linear(ops.layernorm(x, *self.ln1), self.in_proj)            # [P, 2*Dm] = x | z
+        pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"
+        n1 = ops.layernorm(x, *self.ln1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.ln1)
+        xz = ops.linear(n1, self.in_proj)                                     # [P, 2*Dm] = x | z
         u = ops.dwconv2d(to_map(xz[:, :Dm], B, H, W), self.dw, act=ACT_SILU)  # [B,H,W,Dm]
         ut = tokens(u)
         xdbl = ops.linear(ut, self.x_proj)                                    # [P, 4*(R+32)]
         y4 = ops.selective_scan4(ut, xdbl, self.dtw, self.dtb, self.A, self.Ds, B, H, W, Dm, self.R)
-        g = ops.mamba_norm_gate(y4, xz[:, Dm:], *self.out_norm)               # LN(sum y) * silu(z)
-        y = ops.linear(g, self.out_proj, res=x, rvec=self.skip1)              # x * skip_scale + out_proj(.)
-        c2, att = self.cab(to_map(ops.layernorm(y, *self.ln2), B, H, W))
+        g = ops.mamba_norm_gate(y4, xz[:, Dm:], *self.out_norm, out_planes=True if pl else None, want_f32=not pl)
+        y = ops.linear(g, self.out_proj, res=x, rvec=self.skip1)              # x * skip_scale + out_proj(LN(sum y) * silu(z))
+        if pl:
+            c2, att = self.cab(ops.layernorm(y, *self.ln2, out_planes=True, want_f32=False).reshape_map(B, H, W))
+        else:
+            c2, att = self.cab(to_map(ops.layernorm(y, *self.ln2), B, H, W))
         return ops.scale_add(y, tokens(c2), avec=self.skip2, bvec=att, rows_per_batch=H * W)
 
 
@@ -78,5 +83,4 @@ class MambaIR:
             for blk in blocks:
                 r = blk(r, B, H, W)
             t = tokens(ops.conv2d(to_map(r, B, H, W), conv, res=to_map(t, B, H, W)))
-        t = ops.layernorm(t, *self.norm)
-        return self.tail(to_map(t, B, H, W), x0)
+        return self.tail(ops.final_norm(t, self.norm, B, H, W), x0)

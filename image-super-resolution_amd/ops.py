@@ -209,17 +209,22 @@ def zero_page(device) -> torch.Tensor:
     return _ZEROS[key]
 
 
-def planes_bn(N: int) -> int:
-    """Column tile of the planes GEMM: least padded N, the wider tile on ties."""
+def planes_tile(M: int, N: int, K: int):
+    """(bm, bn, stages) of the planes GEMM (measured on MI355X, tools/planes_bench.py): least padded N weighted by the
+    tile's efficiency (192 > 128 > 64 columns); 256-row tiles only pay on long-K shapes with many row tiles."""
     best = None
-    for bn in (192, 128, 64):
-        padded = (N + bn - 1) // bn * bn
-        if best is None or padded < best[0]:
-            best = (padded, bn)
-    return best[1]
+    for bn, eff in ((192, 1.0), (128, 0.95), (64, 0.8)):
+        cost = (N + bn - 1) // bn * bn / eff
+        if best is None or cost < best[0]:
+            best = (cost, bn)
+    bn = best[1]
+    if bn == 128 and K >= 512 and M >= 256 * 1024:
+        return 256, 128, 3
+    return 128, bn, 2
 
 
 PLANES_ACTS = (ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU)
+PLANES_AUTO = os.environ.get("FFSR_PLANES", "1") != "0"   # FFSR_PLANES=0: every GEMM takes its fp32 input directly
 
 
 def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
@@ -236,6 +241,11 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
     else:
         oshape = (B, Ho, Wo, cv.N)
     is_planes = isinstance(x, Planes)
+    if (not is_planes and PLANES_AUTO and GEMM_MODE == "bf16x3" and not shuffle and akscale is None and tile_hint == 0
+            and act in PLANES_ACTS and cv.KH * cv.KW > 1 and cv.stride == 1 and cv.Cin_true >= 32 and cv.N > 64 and B * Ho * Wo >= 16384):
+        # long-K conv on an fp32 map: one extra split pass (read + write of the input) buys the ~1.5x faster planes GEMM
+        x = split_planes(widen(x, cv.Cin_true) if x.shape[3] != cv.Cin_true else x)
+        is_planes = True
     if out_planes is True:
         out_planes = Planes(B, Ho, Wo, cv.N, x.buf.device if is_planes else x.device)
     if out_planes is not None and not is_planes:
@@ -263,7 +273,7 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
                  None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
                  0 if out_planes is None else out_planes.Cp, B, H, W, cv.N, 0 if out is None else ld(out), ldr, cv.KH,
                  cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope), float(cscale), float(rscale),
-                 bm, bn or planes_bn(cv.N), stages, _stream())
+                 *((bm or 128, bn, stages) if bn else planes_tile(B * Ho * Wo, cv.N, cv.KH * cv.KW * x.Cp)), _stream())
     else:
         ldi = ld(x)
         assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"
@@ -285,7 +295,7 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true,
-                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH),
+                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH, int(is_planes)),
                      4.0 * (B * H * W * cv.Cin_true + cv.N * cv.KH * cv.KW * cv.Cin_true
                             + B * Ho * Wo * cv.N * (2 if res is not None else 1))))
     if out_planes is not None:
@@ -345,6 +355,15 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None, out_plan
              0 if out is None else _mat(out)[3], _ptr(out_planes.hi), _ptr(out_planes.lo), out_planes.Cp, _ptr(r1[0]), r1[3],
              _ptr(r2[0]), r2[3], M, C, _stream())
     return (out, out_planes) if out is not None else out_planes
+
+
+def final_norm(t2d, norm, B, H, W):
+    """Last LayerNorm of a Swin-family body -> the input of conv_after_body: planes (when enabled) or an fp32 map."""
+    if PLANES_AUTO and GEMM_MODE == "bf16x3":
+        return layernorm(t2d, *norm, out_planes=True, want_f32=False).reshape_map(B, H, W)
+    t = layernorm(t2d, *norm)
+    s = t.stride(0)
+    return t.as_strided((B, H, W, t.shape[1]), (H * W * s, W * s, s, 1), t.storage_offset())
 
 
 def unary(x, act=ACT_NONE, slope=0.0, pre=1.0, alpha=1.0, beta=0.0, cscale=None, cbias=None, clamp=None, out=None):
@@ -515,13 +534,18 @@ def selective_scan4(u, xdbl, dtw, dtb, A, Dv, B, H, W, Dm, R, chunk=None):
     return y
 
 
-def mamba_norm_gate(y4, z, gamma, beta, eps=1e-5, out=None):
-    """y4 [4, M, C], z [M, C] (row stride ldz) -> LayerNorm(sum_k y4[k]) * silu(z)"""
+def mamba_norm_gate(y4, z, gamma, beta, eps=1e-5, out=None, out_planes=None, want_f32=True):
+    """y4 [4, M, C], z [M, C] (row stride ldz) -> LayerNorm(sum_k y4[k]) * silu(z); out_planes as in layernorm()."""
     _, M, C = y4.shape
-    if out is None:
+    if out_planes is True:
+        out_planes = Planes(1, 1, M, C, y4.device)
+    if out is None and (want_f32 or out_planes is None):
         out = torch.empty(M, C, device=y4.device)
-    hip.call("ffsr_mamba_norm_gate_f32", _ptr(y4), M * C, C, _ptr(z), _mat(z)[3], _ptr(gamma), _ptr(beta), float(eps),
-             _ptr(out), _mat(out)[3], M, C, _stream())
+    hip.call("ffsr_mamba_norm_gate_planes_f32", _ptr(y4), M * C, C, _ptr(z), _mat(z)[3], _ptr(gamma), _ptr(beta), float(eps),
+             _ptr(out), 0 if out is None else _mat(out)[3], None if out_planes is None else _ptr(out_planes.hi),
+             None if out_planes is None else _ptr(out_planes.lo), 0 if out_planes is None else out_planes.Cp, M, C, _stream())
+    if out_planes is not None:
+        return (out, out_planes) if out is not None else out_planes
     return out
 
 

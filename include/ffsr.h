@@ -171,6 +171,12 @@ int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xdbl, int ldx
 int ffsr_mamba_norm_gate_f32(const float* y, long long ystride, int ldy, const float* z, int ldz, const float* gamma,
                              const float* beta, float eps, float* out, int ldo, int M, int C, void* stream);
 
+/* ffsr_mamba_norm_gate_f32 that can also (or only) emit the result as bf16 hi / lo planes [M, ldp] for the out_proj
+ * GEMM (ffsr_conv2d_planes); out may be NULL when the planes are given. */
+int ffsr_mamba_norm_gate_planes_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
+                                    const float* gamma, const float* beta, float eps, float* out, int ldo, void* out_hi,
+                                    void* out_lo, int ldp, int M, int C, void* stream);
+
 /* Phase-2 band split into bands[pixel][9][4] (ldb = 36): multi_domain_frequency.py:146-196 (DCT), :251-299 (DWT,
  * sub [B, Hd, Wd, 16] then upsampled with ffsr_bilinear_f32), :352-385 (FFT, as separable dense DFTs;
  * twW/twH = (cos, sin)(2 pi j / n) tables, mask [H, W/2+1], work = 10 * B*3*H*(W/2+1) floats). */
