@@ -165,14 +165,20 @@ __global__ __launch_bounds__(256, (QT == 1 ? (DT == 1 ? 4 : (DT == 2 ? 3 : 2)) :
         // relative position bias: table[(qy - ky + ws-1) * (2ws-1) + (qx - kx + ws-1)]  (drct_arch.py:148-158,188-191)
         const int q = q0 + qt * 32 + r32;
         const int qidx = (q / WS + WS - 1) * span + (q % WS) + WS - 1;
+        // (one base pointer per tile and compile-time offsets: all 16 table reads are issued as one batch)
+        const float* rb = rpb + (qidx - (kt * 4 + ks * 2) * span - 4 * hh);
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = rb[-((e >> 3) * span + (e & 3) + 8 * ((e >> 2) & 1))];
+        if (use_mask) {   // workgroup-uniform
+#pragma unroll
+          for (int e = 0; e < 16; ++e) bv[e] += tok_reg[key0 + (e & 3) + 8 * (e >> 2)] != qreg[qt] ? -100.0f : 0.f;
+        }
         float mx = -3.0e38f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int key = key0 + (e & 3) + 8 * (e >> 2);
-          float v = s[qt][e] + rpb[qidx - (key / WS) * span - (key % WS)];
-          if (use_mask && tok_reg[key] != qreg[qt]) v += -100.0f;
-          s[qt][e] = v;
-          mx = fmaxf(mx, v);
+          s[qt][e] += bv[e];
+          mx = fmaxf(mx, s[qt][e]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(mrow[qt], mx);
@@ -216,6 +222,264 @@ __global__ __launch_bounds__(256, (QT == 1 ? (DT == 1 ? 4 : (DT == 2 ? 3 : 2)) :
         if (d < hd) orow[d] = o[i][qt][e] * inv;
       }
   }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// (1b) The same attention with both contractions on the bf16 MFMA as 3-term split products (x = hi + lo in bf16,
+// x*y ~ hi*hi + hi*lo + lo*hi, fp32 accumulate: ~1e-5 relative, the arithmetic of ffsr_conv2d_bf16x3) -- 16x the f32
+// MFMA rate at 3 instructions per product.  Same decomposition as window_attn_kernel<DT, 1> (128 queries per
+// workgroup, S^T = K Q^T so the query sits on the lane, flash-style over 64-key tiles); what changes is the operand
+// staging: K (and Q) tiles live in LDS as bf16 hi / lo planes [key][d], V as TRANSPOSED planes [d][key], because the
+// second product O^T += V^T P^T takes P^T straight from the S^T accumulator registers (registers 8s..8s+7 of a lane,
+// converted pairwise, are the B fragment of k-step s) and that fixes the key order of the A fragment to
+// key = 16s + 8(j>>2) + 4h + (j&3) for element j of lane half h: two 8-byte reads of a V^T row.
+// --------------------------------------------------------------------------------------------------------------
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned auintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned auintx4 __attribute__((ext_vector_type(4)));
+
+// NW = 4: 128 queries per workgroup, 2 workgroups per (window, head), each staging all K / V tiles;
+// NW = 8: one 512-thread workgroup per (window, head): K / V are fetched and split once.
+template <int KS, int NW>   // head_dim padded to 16 * KS; NW waves of 32 queries
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (KS <= 2 ? 4 : (KS <= 4 ? 3 : 2)))) void window_attn_x3_kernel(WinArgs p) {
+  constexpr int NT = 64 * NW;           // threads
+  constexpr int RPW = 64 / NW;          // rows of a 64-token tile staged by one wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  constexpr int HDP = 16 * KS, DT = (KS + 1) / 2;
+  constexpr int WS = 16, N = WS * WS;
+  constexpr int RSK = HDP * 2 + 16;   // K / Q plane row stride in bytes: an odd number of 16-byte slots -> b128 reads conflict-free
+  constexpr int RSV = 136;            // V^T plane row stride: 64 keys * 2 B + 8 -> b64 reads of 32 rows conflict-free
+  constexpr int KPL = 64 * RSK, VPL = DT * 32 * RSV;
+  unsigned char* Khi = ldsb;
+  unsigned char* Klo = Khi + KPL;
+  unsigned char* Vhi = Klo + KPL;
+  unsigned char* Vlo = Vhi + VPL;
+  int* tok_pix = reinterpret_cast<int*>(Vlo + VPL);
+  unsigned char* tok_reg = reinterpret_cast<unsigned char*>(tok_pix + N);   // [N] region id of every window token (bytes)
+  float* rpb = reinterpret_cast<float*>(tok_reg + N);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware work order (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so the workgroups of one XCD
+  // take a contiguous range of (window, query half, head) triples with the head fastest -- all heads of a window read
+  // the same qkv rows (each head only hd of the 3C floats of a row), which then stay in ONE L2.
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  constexpr int NZ = NW == 4 ? 2 : 1;
+  const int head = logical % p.heads;
+  const int zq = (logical / p.heads) % NZ;            // which 128-query half (NW = 4)
+  const int wlin = logical / (p.heads * NZ);          // window index over the batch
+  const int nwx = p.W / WS, nwy = p.H / WS;
+  const int win = wlin % (nwx * nwy), b = wlin / (nwx * nwy);
+  const int wy = win / nwx, wx = win % nwx;
+  for (int t = tid; t < N; t += NT) {
+    int py = t / WS, px = t % WS;
+    int ys = wy * WS + py, xs = wx * WS + px;  // position in the rolled image
+    int y = ys + p.shift, x = xs + p.shift;
+    if (y >= p.H) y -= p.H;
+    if (x >= p.W) x -= p.W;
+    tok_pix[t] = (b * p.H + y) * p.W + x;
+    tok_reg[t] = (unsigned char)(p.masked ? region_id(ys, p.H, WS, p.shift) * 3 + region_id(xs, p.W, WS, p.shift) : 0);
+  }
+  const bool use_mask = p.masked && (wy == nwy - 1 || wx == nwx - 1);
+  const int span = 2 * WS - 1;
+  for (int t = tid; t < span * span; t += NT) rpb[t] = p.bias[(size_t)t * p.heads + head];
+  const int hd = p.hd;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const float* qbase = p.qkv + head * hd;
+  const int q0 = (NW == 4 ? zq * 128 : 0) + wave * 32;   // first query (window token) of this wave
+
+  // ---- row loader (K tile / Q round): 64 tokens -> bf16 hi / lo planes [64][RSK]; lane = channel pair (2l, 2l+1).
+  // All global loads of a batch are issued before the conversions (clamped column + 0/1 mask, no branches around loads).
+  const int d0 = 2 * lane;
+  const float m0 = d0 < hd ? 1.f : 0.f, m1 = d0 + 1 < hd ? 1.f : 0.f;
+  const int c0 = min(d0, hd - 1), c1 = min(d0 + 1, hd - 1);
+  auto load_rows = [&](int tok0, int col0, float scale) {
+#pragma unroll 1
+    for (int batch = 0; batch < RPW / 8; ++batch) {
+      float reg[8][2];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int rr = wave + NW * (batch * 8 + r);
+        const float* src = qbase + (size_t)tok_pix[tok0 + rr] * p.ldq + col0;
+        reg[r][0] = src[c0];
+        reg[r][1] = src[c1];
+      }
+      if (d0 < HDP) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int rr = wave + NW * (batch * 8 + r);
+          unsigned h, l;
+          ffsr_split2(reg[r][0] * m0 * scale, reg[r][1] * m1 * scale, h, l);
+          *reinterpret_cast<unsigned*>(Khi + rr * RSK + lane * 4) = h;
+          *reinterpret_cast<unsigned*>(Klo + rr * RSK + lane * 4) = l;
+        }
+      }
+    }
+  };
+  // ---- K / V tile loader: 64 tokens -> K planes [64][RSK] (as load_rows) and TRANSPOSED V planes [d][64 keys]
+  // (lane = channel, this wave's RPW keys as packed pairs).  Every global load of the tile is issued before the first
+  // conversion, so the workgroup pays ONE exposed memory latency per tile.
+  constexpr int DI = HDP > 64 ? 2 : 1;
+  auto load_kv = [&](int tok0) {
+    float kreg[RPW][2], vreg[DI][RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const float* src = qbase + (size_t)tok_pix[tok0 + wave + NW * r] * p.ldq + p.C;
+      kreg[r][0] = src[c0];
+      kreg[r][1] = src[c1];
+    }
+#pragma unroll
+    for (int di = 0; di < DI; ++di) {
+      const int cc = min(lane + 64 * di, hd - 1);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) vreg[di][r] = (qbase + (size_t)tok_pix[tok0 + RPW * wave + r] * p.ldq + 2 * p.C)[cc];
+    }
+    if (d0 < HDP) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int rr = wave + NW * r;
+        unsigned h, l;
+        ffsr_split2(kreg[r][0] * m0, kreg[r][1] * m1, h, l);
+        *reinterpret_cast<unsigned*>(Khi + rr * RSK + lane * 4) = h;
+        *reinterpret_cast<unsigned*>(Klo + rr * RSK + lane * 4) = l;
+      }
+    }
+#pragma unroll
+    for (int di = 0; di < DI; ++di) {
+      const int d = lane + 64 * di;
+      const float mk = d < hd ? 1.f : 0.f;
+      if (d < DT * 32) {
+#pragma unroll
+        for (int pr = 0; pr < RPW / 2; ++pr) {
+          unsigned h, l;
+          ffsr_split2(vreg[di][2 * pr] * mk, vreg[di][2 * pr + 1] * mk, h, l);
+          *reinterpret_cast<unsigned*>(Vhi + d * RSV + (RPW * wave + 2 * pr) * 2) = h;
+          *reinterpret_cast<unsigned*>(Vlo + d * RSV + (RPW * wave + 2 * pr) * 2) = l;
+        }
+      }
+    }
+  };
+
+  // ---- Q fragments (B operand of S^T = K Q^T) -> registers, staged 64 queries at a time through the K planes
+  abf16x8 qh[KS], ql[KS];
+  for (int round = 0; round < NW / 2; ++round) {
+    __syncthreads();
+    load_rows((NW == 4 ? zq * 128 : 0) + round * 64, 0, p.scale);
+    __syncthreads();
+    if ((wave >> 1) == round) {
+      const int row = (wave & 1) * 32 + r32;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qh[ks] = *reinterpret_cast<const abf16x8*>(Khi + row * RSK + (16 * ks + 8 * hh) * 2);
+        ql[ks] = *reinterpret_cast<const abf16x8*>(Klo + row * RSK + (16 * ks + 8 * hh) * 2);
+      }
+    }
+  }
+  const int qreg = tok_reg[q0 + r32];
+
+  floatx16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float mrow = -3.0e38f, lrow = 0.f;
+  const int q = q0 + r32;
+  const int qidx = (q / WS + WS - 1) * span + (q % WS) + WS - 1;
+
+#pragma unroll 1
+  for (int kt = 0; kt < N / 64; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    load_kv(kt * 64);
+    __syncthreads();
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      // S^T[32 keys][32 queries]
+      floatx16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      const unsigned char* kr = Khi + (sub * 32 + r32) * RSK + 16 * hh;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const abf16x8 kh = *reinterpret_cast<const abf16x8*>(kr + 32 * ks);
+        const abf16x8 kl = *reinterpret_cast<const abf16x8*>(kr + KPL + 32 * ks);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s, 0, 0, 0);
+      }
+      // relative position bias: table[(qy - ky + ws-1) * (2ws-1) + (qx - kx + ws-1)]  (drct_arch.py:148-158,188-191).
+      // key = key0 + (e&3) + 8*(e>>2) with key0 = 64 kt + 32 sub + 4 hh, so ky = 4 kt + 2 sub + (e>>3) and
+      // kx = 4 hh + (e&3) + 8*((e>>2)&1): one base pointer per sub-tile, compile-time offsets, all 16 reads in one batch
+      const int key0 = kt * 64 + sub * 32 + 4 * hh;
+      const float* rb = rpb + (qidx - (kt * 4 + sub * 2) * span - 4 * hh);
+      float bv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bv[e] = rb[-((e >> 3) * span + (e & 3) + 8 * ((e >> 2) & 1))];
+      if (use_mask) {   // workgroup-uniform; region ids of 4 consecutive keys in one 32-bit read
+        unsigned rg[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rg[g] = *reinterpret_cast<const unsigned*>(tok_reg + key0 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] += (((rg[e >> 2] >> (8 * (e & 3))) & 0xffu) != (unsigned)qreg) ? -100.0f : 0.f;
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] += bv[e];
+        mx = fmaxf(mx, s[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrow, mx);
+      const float corr = __expf(mrow - mnew);
+      mrow = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] = __expf(s[e] - mnew);
+        ps += s[e];
+      }
+      lrow = lrow * corr + ps;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= corr;
+      // P^T fragments of the two 16-key steps, straight from the accumulator registers
+      abf16x8 ph[2], pl[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        unsigned h4[4], l4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ffsr_split2(s[8 * st + 2 * c], s[8 * st + 2 * c + 1], h4[c], l4[c]);
+        ph[st] = __builtin_bit_cast(abf16x8, auintx4{h4[0], h4[1], h4[2], h4[3]});
+        pl[st] = __builtin_bit_cast(abf16x8, auintx4{l4[0], l4[1], l4[2], l4[3]});
+      }
+      // O^T[d][query] += V^T[d][key] P^T[key][query]; element j of lane half h <-> key 16 st + 8 (j >> 2) + 4 h + (j & 3)
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const unsigned char* vr = Vhi + (i * 32 + r32) * RSV + (sub * 32 + 4 * hh) * 2;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const auintx2 a0 = *reinterpret_cast<const auintx2*>(vr + 32 * st), a1 = *reinterpret_cast<const auintx2*>(vr + 32 * st + 16);
+          const auintx2 b0 = *reinterpret_cast<const auintx2*>(vr + VPL + 32 * st), b1 = *reinterpret_cast<const auintx2*>(vr + VPL + 32 * st + 16);
+          const abf16x8 vh = __builtin_bit_cast(abf16x8, auintx4{a0[0], a0[1], a1[0], a1[1]});
+          const abf16x8 vl = __builtin_bit_cast(abf16x8, auintx4{b0[0], b0[1], b1[0], b1[1]});
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[st], o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[st], o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[st], o[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- normalise and store O^T: lane = query, registers = head-dim rows
+  const float inv = 1.0f / (lrow + __shfl_xor(lrow, 32, 64));
+  float* orow = p.out + (size_t)tok_pix[q0 + r32] * p.ldo + head * hd;
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int d = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (d < hd) orow[d] = o[i][e] * inv;
+    }
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -474,6 +738,8 @@ __global__ void pixel_mha_kernel(const float* __restrict__ qkv, int ldq, float* 
   }
 }
 
+inline bool grid_ok(long long y) { return y > 0 && y <= 65535; }
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -490,14 +756,45 @@ extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias
   a.shift = shift; a.heads = heads; a.hd = hd; a.hdp = (hd + 7) / 8 * 8; a.masked = shift > 0; a.scale = scale;
   const int N = ws * ws;
   FFSR_CHECK(ws == 16);
+  FFSR_CHECK(grid_ok((H / ws) * (W / ws) * B));
+  if (variant == 0 || variant == 4) {
+    // split-bf16 MFMA kernel (default)
+    const int KS = (hd + 15) / 16, DTx = (KS + 1) / 2;
+    const size_t ldsx = (size_t)2 * 64 * (KS * 32 + 16) + (size_t)2 * DTx * 32 * 136 + N * 4 + N +
+                        (size_t)(2 * ws - 1) * (2 * ws - 1) * 4;
+    const bool wide = variant == 4;   // 0: two 256-thread workgroups per (window, head); 4: one 512-thread workgroup
+    dim3 gridx((unsigned)(heads * (H / ws) * (W / ws) * B * (wide ? 1 : 2)));
+#define LAUNCH_X3(K)                                                                                                  \
+  {                                                                                                                   \
+    if (ldsx > 64 * 1024) {                                                                                           \
+      (void)hipFuncSetAttribute((const void*)window_attn_x3_kernel<K, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)ldsx);                                                                           \
+      (void)hipFuncSetAttribute((const void*)window_attn_x3_kernel<K, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)ldsx);                                                                           \
+    }                                                                                                                 \
+    if (wide) hipLaunchKernelGGL((window_attn_x3_kernel<K, 8>), gridx, dim3(512), ldsx, ST, a);                        \
+    else hipLaunchKernelGGL((window_attn_x3_kernel<K, 4>), gridx, dim3(256), ldsx, ST, a);                             \
+  }
+    switch (KS) {
+      case 1: LAUNCH_X3(1); break;
+      case 2: LAUNCH_X3(2); break;
+      case 3: LAUNCH_X3(3); break;
+      case 4: LAUNCH_X3(4); break;
+      case 5: LAUNCH_X3(5); break;
+      case 6: LAUNCH_X3(6); break;
+      case 7: LAUNCH_X3(7); break;
+      default: LAUNCH_X3(8); break;
+    }
+#undef LAUNCH_X3
+    return ffsr_launch_status();
+  }
   const size_t lds = (size_t)(128 * (a.hdp + 4) + 64) * 4 + 2 * N * 4 + (size_t)(2 * ws - 1) * (2 * ws - 1) * 4;
   FFSR_CHECK(lds <= 160 * 1024);
   const int DT = (hd + 31) / 32;
-  // QT = 1 (128 queries per workgroup, 2 workgroups per window-head) keeps the register file small enough for 2+
-  // waves per SIMD at the large head dims; QT = 2 loads K/V once per window-head (best for small head dims).
-  const int QT = (variant == 1 || variant == 2) ? variant : 1;   // measured: QT = 1 is 20-35 % faster at every head dim
+  // exact f32-MFMA kernel (variant 1 / 2 / 3).  QT = 1 (128 queries per workgroup, 2 workgroups per window-head) keeps
+  // the register file small enough for 2+ waves per SIMD at the large head dims; QT = 2 loads K/V once per window-head.
+  const int QT = variant == 2 ? 2 : 1;   // measured: QT = 1 is 20-35 % faster at every head dim
   dim3 grid(heads, (H / ws) * (W / ws) * B, QT == 1 ? 2 : 1);
-  FFSR_CHECK(grid.y <= 65535);
 #define LAUNCH_WIN(D, Q)                                                                                            \
   {                                                                                                                 \
     if (lds > 64 * 1024)                                                                                            \

@@ -484,10 +484,13 @@ def avgpool2(x, out=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention / scan
-def window_attn(qkv, bias, B, H, W, C, heads, ws, shift, scale, out=None, variant=0):
-    """qkv [B*H*W, 3C] -> [B*H*W, C]"""
+def window_attn(qkv, bias, B, H, W, C, heads, ws, shift, scale, out=None, variant=None):
+    """qkv [B*H*W, 3C] -> [B*H*W, C].  variant None: split-bf16 MFMA kernel in the default GEMM mode, the exact f32-MFMA
+    kernel in FFSR_GEMM_MODE=f32; 0 / 3 force one of them (2: the exact kernel with 256 queries per workgroup)."""
     if out is None:
         out = torch.empty(B * H * W, C, device=qkv.device)
+    if variant is None:
+        variant = 0 if GEMM_MODE == "bf16x3" else 3
     hip.call("ffsr_window_attn_f32", _ptr(qkv), _mat(qkv)[3], _ptr(bias), _ptr(out), _mat(out)[3], B, H, W, C, heads,
              ws, shift, float(scale), variant, _stream())
     return out

@@ -139,7 +139,9 @@ int ffsr_dihedral_f32(const float* in, int ldi, float* out, int ldo, int B, int 
 
 /* DRCT (shifted) window attention, fused: softmax(q k^T * scale + bias (+ shift mask)) v.
  * qkv [B*H*W, ldq]: q | k | v, each [heads][C/heads]; bias = relative_position_bias_table [(2ws-1)^2, heads] (ws = 16); roll / window
- * partition / reverse / mask folded into addressing.  variant: 0 = automatic, 1 / 2 = 128 / 256 queries per workgroup.
+ * partition / reverse / mask folded into addressing.  variant: 0 = split-bf16 MFMA kernel, 128 queries per workgroup (4: 256 queries per workgroup; both
+ * contractions as 3-term bf16 products, fp32 accumulate, ~1e-5 relative: the arithmetic of ffsr_conv2d_bf16x3),
+ * 3 (or 1) = exact f32-MFMA kernel with 128 queries per workgroup, 2 = exact kernel with 256 queries per workgroup.
  * Replaces drct_arch.py:175-206 and :376-414. */
 int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* out, int ldo, int B, int H, int W, int C,
                          int heads, int ws, int shift, float scale, int variant, void* stream);
