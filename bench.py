@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=H_LR)
     ap.add_argument("--width", type=int, default=W_LR)
+    ap.add_argument("--lanes", type=int, default=1, help="stream lanes: images in flight per GPU (1 or 2)")
     ap.add_argument("--batch", type=int, default=1, help="images per step per GPU (BASELINE config 3 uses 16 x 64x64)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,8 +120,13 @@ def main():
         log(f"warm-up step {i} done")
     barrier()
     t0 = time.perf_counter()
+    outs = []
     for i in range(args.steps):
-        eng.process(lrs[i % len(lrs)])
+        # consecutive steps go to alternate stream lanes (two images in flight); --lanes 1 serialises them
+        outs.append(eng.process(lrs[i % len(lrs)], lane=(i % args.lanes) if args.lanes > 1 else None))
+        if len(outs) > 2:
+            outs.pop(0)
+    eng.join()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -168,35 +174,54 @@ def main():
             log(f"  {name:7s} {1e3 * (time.perf_counter() - t2):8.1f} ms")
         log(f"  conv/GEMM kernel: {len(prof)} launches, {flops / 1e12:.2f} TFLOP, {conv_s * 1e3:.1f} ms -> {achieved:.1f} TFLOP/s; "
             f"whole step {step_s * 1e3:.1f} ms")
+    # ---- the dominant kernel FAMILY: conv / GEMM launches are grouped by the kernel that served them
+    # (prof entry: shape[4] = 1 for the pre-split-input planes GEMM, 0 for the fp32-input kernel)
+    fams = {}
+    for (e0, e1, f, shape, nbytes), ms in zip(prof, dur_ms):
+        t = fams.setdefault(int(shape[4]), [0, 0.0, 0.0, 0.0])
+        t[0] += 1; t[1] += ms; t[2] += f; t[3] += nbytes
     if ops.GEMM_MODE == "bf16x3":
-        kname = "conv_gemm_bf16x3_v3_kernel (implicit GEMM; fp32 operands as 3-term split-bf16 MFMA products, fp32 accumulate)"
+        names = {1: ("conv_gemm_planes_kernel", "conv_gemm_planes_kernel (implicit GEMM, operands pre-split into bf16 hi/lo planes, "
+                     "LDS-DMA staging; products as 3-term split-bf16 MFMA, fp32 accumulate)"),
+                 0: ("conv_gemm_bf16x3_v3_kernel", "conv_gemm_bf16x3_v3_kernel (implicit GEMM; fp32 operands split on the fly, "
+                     "3-term split-bf16 MFMA, fp32 accumulate)")}
         mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
     else:
-        kname, mfma_peak = "conv_gemm_kernel (f32-input MFMA implicit GEMM)", MFMA_F32_PEAK_TFLOPS
+        names = {0: ("conv_gemm_kernel", "conv_gemm_kernel (f32-input MFMA implicit GEMM)")}
+        mfma_peak = MFMA_F32_PEAK_TFLOPS
+    dom = max(fams, key=lambda k: fams[k][1])
+    n_l, dom_ms, dom_flops, dom_bytes = fams[dom]
+    ksym, kname = names[dom]
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv_gemm.json")
-    if ops.GEMM_MODE == "bf16x3" and (h, w) == (H_LR, W_LR) and os.path.exists(tfile):
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if (h, w) == (H_LR, W_LR) and args.batch == 1 and os.path.exists(tfile):
         # PMC counters cannot be read from inside this process: the per-launch HBM bytes come from the committed
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (corrected as the guide prescribes)
-        traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
-        traffic_src = "profiles/r01_pmc_traffic_conv_gemm.json"
-    n_l = len(prof)
-    mean_s = conv_s / n_l
-    bytes_l, flops_l = algo_bytes / n_l, flops / n_l
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py; corrected as the
+        # guide prescribes: FETCH_SIZE x2 on gfx950)
+        ent = json.load(open(tfile)).get(ksym)
+        if ent:
+            traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+    mean_s = dom_ms / 1e3 / n_l
+    bytes_l, flops_l = dom_bytes / n_l, dom_flops / n_l
     gbps = bytes_l / mean_s / 1e9
+    dom_tflops = dom_flops / (dom_ms / 1e3) / 1e12
     # the binding roofline of the average launch = the larger of its two lower bounds
     t_mfma, t_hbm = flops_l / (mfma_peak * 1e12), bytes_l / (HBM_PEAK_GBPS * 1e9)
     if t_hbm >= t_mfma:
         roofline = {"kernel": kname, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": gbps / HBM_PEAK_GBPS}
     else:
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
-                    "frac": achieved / mfma_peak}
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": dom_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
+                    "frac": dom_tflops / mfma_peak}
     roofline.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_l,
                      "algorithmic_flops_per_launch": flops_l, "launches_per_step": n_l, "mean_launch_us": mean_s * 1e6,
-                     "mfma_view": {"achieved_tflops": achieved, "peak_tflops": mfma_peak, "frac": achieved / mfma_peak},
+                     "mfma_view": {"achieved_tflops": dom_tflops, "peak_tflops": mfma_peak, "frac": dom_tflops / mfma_peak},
                      "hbm_view": {"achieved_gbps": gbps, "peak_gbps": HBM_PEAK_GBPS, "frac": gbps / HBM_PEAK_GBPS},
-                     "kernel_share_of_step": conv_s / step_s})
+                     "kernel_share_of_step": dom_ms / 1e3 / step_s,
+                     "all_conv_gemm_launches": {"launches": len(prof), "tflop": flops / 1e12, "ms": conv_s * 1e3,
+                                                "tflops": achieved, "share_of_step": conv_s / step_s,
+                                                "by_kernel": {names[k][0]: {"launches": v[0], "ms": v[1], "tflops": v[2] / v[1] / 1e9}
+                                                              for k, v in fams.items()}}})
 
     if rank == 0:
         line = {"metric": f"SR output megapixels/s (x4, {w}x{h} LR -> {w * SCALE}x{h * SCALE}, full 4-expert + 7-phase fusion)",

@@ -8,7 +8,8 @@
 //   A[m, (tap, c)] = in[pixel(m) + tap offset, c]   (zero page for out-of-image taps / rows >= M)
 //
 // Tile: BM x BN (BM = 128 / 256, BN = 64 / 128 / 192 / 256), BM/64 x 2 waves, wave tile 64 x BN/2 (2 x TN MFMA tiles of
-// 32x32).  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
+// 32x32).  Measured and rejected: delaying the second-resident workgroups by half a tile time (de-phasing the load and
+// store phases of the two workgroups of a CU) changes nothing.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
 // ~16 B/clk/CU), not the matrix pipe, is what bounds the 128-row tile on long-K shapes.
 // LDS image of one stage: A_hi | A_lo | B_hi | B_lo, rows of 64 B (32 bf16), no padding: one LDS-DMA instruction
 // writes 16 rows x 64 B lane-linear.  Bank conflicts are removed on the SOURCE side: the 16-byte chunk c of row r is
@@ -26,6 +27,19 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// tools/planes_probe builds this file with -DFFSR_PLANES_PROBE: s_memtime stamps per workgroup (diagnostic only; the
+// product library is built without it and carries no stamp code).
+#ifdef FFSR_PLANES_PROBE
+#define FFSR_STAMP(i)                                                                         \
+  do {                                                                                        \
+    unsigned long long t_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;            \
+  } while (0)
+#else
+#define FFSR_STAMP(i)
+#endif
 
 struct PlaneArgs {
   const unsigned short* a_hi;   // [B*H*W][Cp]
@@ -46,6 +60,9 @@ struct PlaneArgs {
   int act;
   float slope, cscale, rscale;
   int M, nk;                    // nk = taps * Cp / 32
+#ifdef FFSR_PLANES_PROBE
+  unsigned long long* stamps;   // [grid][8]
+#endif
 };
 
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) { ffsr_split2(x0, x1, hi, lo); }
@@ -85,6 +102,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (a burst of 10 pieces right after the barrier costs 100-185 issue cycles each with the matrix pipe idle).
 template <int BM, int BN, int STAGES, bool GELU, int SCHED>
 __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
+  FFSR_STAMP(0);
   constexpr int NW = BM / 32;                                // waves: (BM / 64) x 2
   constexpr int TM = 2, TN = BN / 64;
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;        // bytes of one plane of one stage
@@ -198,6 +216,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
   const int fo1 = r * 64 + (((2 + h) ^ swz) << 4);
   const int nk = p.nk;
 
+  FFSR_STAMP(1);   // address set-up done
   // ---- prologue: STAGES - 1 K steps in flight
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s, s < nk);   // (steps past nk fetch the zero page: same vmcnt bookkeeping)
@@ -208,6 +227,8 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
     // retire K step kt: STAGES - 2 younger steps stay in flight (steps past nk are zero-page fetches)
     wait_vmcnt<(STAGES - 2) * LOADS>();
     __builtin_amdgcn_s_barrier();   // every wave's pieces of step kt have landed; every wave is done reading stage `is`
+    if (kt == 0) FFSR_STAMP(2);     // first tile landed
+    if (kt == 1) FFSR_STAMP(3);     // first K step computed + second tile landed
     const bool more = kt + STAGES - 1 < nk;
     if (SCHED == 0) issue(is, more);
 
@@ -250,6 +271,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
     if (SCHED == 1) advance();
     if (++is == STAGES) is = 0;
   }
+  FFSR_STAMP(4);                  // main loop done
   wait_vmcnt<0>();                // zero-page fetches of the last steps
   __builtin_amdgcn_s_barrier();   // all fragment reads done: the staging LDS becomes the transpose scratch
 
@@ -347,6 +369,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
       }
     }
   }
+  FFSR_STAMP(5);                  // epilogue done (stores issued)
 }
 
 template <int BM, int BN, int STAGES, bool GELU, int SCHED>
@@ -366,7 +389,10 @@ int launch_planes3(const PlaneArgs& a, hipStream_t st) {
   return ffsr_launch_status();
 }
 
-int g_planes_sched = 1;   // FFSR_PLANES_SCHED (diagnostic): 0 = burst issue, 1 = interleaved issue
+#ifdef FFSR_PLANES_PROBE
+unsigned long long* g_probe_stamps = nullptr;
+#endif
+int g_planes_sched = 1;   // 0 = burst issue (stages + 10, diagnostic), 1 = interleaved issue
 
 template <int BM, int BN, int STAGES, bool GELU>
 int launch_planes2(const PlaneArgs& a, hipStream_t st) {
@@ -450,6 +476,9 @@ extern "C" int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, co
   FFSR_CHECK((long long)n_rows_padded * KH * KW * Cp * 2 < (1ll << 32));         // ... and into the weight planes
   a.M = (int)M;
   a.nk = KH * KW * (Cp / 32);
+#ifdef FFSR_PLANES_PROBE
+  a.stamps = g_probe_stamps;
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (bm == 0) bm = 128;
   if (stages == 0) stages = 2;
@@ -477,3 +506,7 @@ extern "C" int ffsr_split_planes(const float* x, int ldx, void* hi, void* lo, in
                      (unsigned short*)lo, ldp, M, C);
   return ffsr_launch_status();
 }
+
+#ifdef FFSR_PLANES_PROBE
+extern "C" void ffsr_planes_probe_set(unsigned long long* stamps) { g_probe_stamps = stamps; }
+#endif

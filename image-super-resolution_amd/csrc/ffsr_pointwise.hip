@@ -66,16 +66,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Vectorised form (C % 4 == 0, 16-byte aligned rows): HALF a wave per row, 8 channels per lane and pass (two 16-byte
 // loads), NPASS passes cover C <= 256 * NPASS.  Outputs: fp32 `out` (optional) and / or the bf16 hi / lo planes of the
 // result (optional; [M, ldp], ldp % 32 == 0, columns C..ldp-1 written as zeros) for ffsr_conv2d_planes.
-template <int NPASS>
+template <int NPASS, int LPR = 32>   // LPR lanes per row (32, or 16 / 8 for C <= 128 / 64 so that narrow rows fill the wave)
 __global__ __launch_bounds__(256) void layernorm_v8_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                            const float* __restrict__ b, float eps, float* __restrict__ out,
                                                            int ldo, unsigned short* __restrict__ ohi,
                                                            unsigned short* __restrict__ olo, int ldp,
                                                            const float* __restrict__ r1, int ldr1,
                                                            const float* __restrict__ r2, int ldr2, int M, int C) {
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int l = threadIdx.x & 31;
-  if (row >= M) return;     // whole half-waves leave together: the 32-lane shuffles below stay inside a half
+  static_assert(LPR == 32 || NPASS == 1, "narrow rows are single pass");
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  if (row >= M) return;     // whole lane groups leave together: the shuffles below stay inside a group
   const float* xr = x + (size_t)row * ldx;
   floatx4 v[NPASS][2];
   float s = 0.f;
@@ -83,30 +84,30 @@ __global__ __launch_bounds__(256) void layernorm_v8_kernel(const float* __restri
   for (int p = 0; p < NPASS; ++p)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const int c = (p * 32 + l) * 8 + 4 * hh;
+      const int c = (p * LPR + l) * 8 + 4 * hh;
       v[p][hh] = c < C ? *reinterpret_cast<const floatx4*>(xr + c) : floatx4{0.f, 0.f, 0.f, 0.f};
       s += (v[p][hh][0] + v[p][hh][1]) + (v[p][hh][2] + v[p][hh][3]);
     }
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const int c = (p * 32 + l) * 8 + 4 * hh;
+      const int c = (p * LPR + l) * 8 + 4 * hh;
       if (c < C) {
         const floatx4 d = v[p][hh] - mean;
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
       }
     }
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = 1.0f / sqrtf(q / (float)C + eps);
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    const int c0 = (p * 32 + l) * 8;
+    const int c0 = (p * LPR + l) * 8;
     float y[8];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -207,29 +208,49 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int chunk = blockIdx.y, b = blockIdx.z;
   const int per = (R + nchunk - 1) / nchunk;
   const int r0 = chunk * per, r1 = min(R, r0 + per);
-  float s = 0.f;
-  if (c < C)
-    for (int r = r0 + rl; r < r1; r += 4) s += x[((size_t)b * R + r) * ldx + c];
-  red[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    part[((size_t)b * nchunk + chunk) * C + c] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains: the loads of one trip are in flight together
+  if (c < C) {
+    const float* xp = x + (size_t)b * R * ldx + c;
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      s0 += xp[(size_t)r * ldx];
+      s1 += xp[(size_t)(r + 4) * ldx];
+      s2 += xp[(size_t)(r + 8) * ldx];
+      s3 += xp[(size_t)(r + 12) * ldx];
+    }
+    for (; r < r1; r += 4) s0 += xp[(size_t)r * ldx];
   }
+  red[rl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < C)
+    part[((size_t)b * nchunk + chunk) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// out[b, c] = scale * sum_k part[b, k, c]; grid = (ceil(C/64), B), block 256 = 64 channels x 4 chunk lanes
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C,
-                                                            int nchunk, float scale) {
-  __shared__ float red[4][64];
+// out[b, c] = scale * sum_k part[b, k, c]; grid = (ceil(C/64), B), block 1024 = 64 channels x 16 chunk lanes
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C,
+                                                             int nchunk, float scale) {
+  __shared__ float red[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int kl = threadIdx.x >> 6, b = blockIdx.y;
-  float s = 0.f;
-  if (c < C)
-    for (int k = kl; k < nchunk; k += 4) s += part[((size_t)b * nchunk + k) * C + c];
-  red[kl][threadIdx.x & 63] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* pp = part + (size_t)b * nchunk * C + c;
+    int k = kl;
+    for (; k + 48 < nchunk; k += 64) {
+      s0 += pp[(size_t)k * C];
+      s1 += pp[(size_t)(k + 16) * C];
+      s2 += pp[(size_t)(k + 32) * C];
+      s3 += pp[(size_t)(k + 48) * C];
+    }
+    for (; k < nchunk; k += 16) s0 += pp[(size_t)k * C];
+  }
+  red[kl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (kl == 0 && c < C)
-    out[(size_t)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale;
+  if (kl == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
+    out[(size_t)b * C + c] = s * scale;
+  }
 }
 
 // ------------------------------------------------------------------------------------------- depthwise conv
@@ -268,52 +289,113 @@ __global__ void dwconv_kernel(const float* __restrict__ in, int ldi, const float
   st<V>(out + pix * ldo + c, acc);
 }
 
-// NAFNet: t = dw3x3(in [.., 2C]) ; out[.., c] = t[c] * t[c + C] ; part[b, chunk, c] = sum over the chunk's pixels
-// grid = (ceil(C/64), nchunk, B); block 256 = 64 channels x 4 pixel lanes; chunk = contiguous pixel range
-__global__ __launch_bounds__(256) void dw3x3_gate_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ out, int ldo,
-                                                         float* __restrict__ part, int H, int W, int C, int nchunk) {
+// Depthwise 3x3 (stride 1, zero padding 1), lane = channel, one wave = a run of consecutive pixels, 4 pixels per trip:
+// the 3 x 6 input window of the trip is fetched with 18 (x2 for the gate) independent, branch-free loads (clamped
+// coordinates, values zeroed by a 0/1 mask: a load under a bounds branch is waited for one at a time), 9 loads per
+// output pixel instead of 18.
+//   GATE (NAFNet, nafnet_arch.py:118-121): t = dw3x3(in [.., 2C]); out[.., c] = t[c] * t[c + C];
+//                                          part[b, chunk, c] = sum of out over the chunk's pixels (SCA pooling)
+//   else (MambaIR, mambair_arch.py:239-247,378): out = act(dw3x3(in [.., C]))
+// grid = (ceil(C/64), nchunk, B); block 256 = 4 waves, each a contiguous quarter of the chunk's pixel range.
+template <bool GATE>
+__global__ __launch_bounds__(256) void dw3x3_run_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                        float* __restrict__ part, int H, int W, int C, int nchunk, int act) {
   __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int pl = threadIdx.x >> 6;
-  const int chunk = blockIdx.y, b = blockIdx.z;
+  constexpr int NH = GATE ? 2 : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give every XCD a contiguous band of the image
+  // (consecutive chunks = vertically adjacent pixels) so that the 3 input rows a chunk needs are shared in ONE L2.
+  // (A float4-per-lane form of this kernel -- 16-byte loads, 64/G pixel runs per wave -- measured 20 % slower: ~200
+  // VGPRs for the 3 x 4 x 2 vector window leave 2 waves per SIMD.)
+  const int nxy = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int q8 = nxy >> 3, r8 = nxy & 7, xcd = lin & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int c = (logical % gridDim.x) * 64 + lane;
+  const bool live = c < C;
+  const int cc = live ? c : C - 1;
+  const int chunk = logical / gridDim.x, b = blockIdx.z;
   const int R = H * W;
   const int per = (R + nchunk - 1) / nchunk;
-  const int r0 = chunk * per, r1 = min(R, r0 + per);
-  float s = 0.f;
-  if (c < C) {
-    float w1[9], w2[9];
+  const int q = (per + 3) / 4;
+  const int r0 = chunk * per + wave * q, r1 = min(min(R, (chunk + 1) * per), r0 + q);
+  const int CW = NH * C;
+  float wt[NH][9], bs[NH];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      w1[k] = w[k * 2 * C + c];
-      w2[k] = w[k * 2 * C + C + c];
-    }
-    const float b1 = bias[c], b2 = bias[C + c];
-    for (int r = r0 + pl; r < r1; r += 4) {
-      int y = r / W, x = r - y * W;
-      float a1 = b1, a2 = b2;
+  for (int hh = 0; hh < NH; ++hh) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[hh][k] = w[k * CW + hh * C + cc];
+    bs[hh] = bias ? bias[hh * C + cc] : 0.f;
+  }
+  const float* inb = in + (size_t)b * R * ldi + cc;
+  float* outb = out + (size_t)b * R * ldo + c;
+  float s = 0.f;
+  for (int r = r0; r < r1; r += 4) {
+    const int y = r / W, x = r - y * W;
+    const int np = min(4, r1 - r);
+    if (x + np <= W) {   // the trip stays inside one image row (wave-uniform)
+      float v[NH][3][6];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        int yy = y + ky - 1;
-        if (yy < 0 || yy >= H) continue;
+        const int yy = y + ky - 1;
+        const bool yok = yy >= 0 && yy < H;
+        const float* rowp = inb + (size_t)min(max(yy, 0), H - 1) * W * ldi;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          int xx = x + kx - 1;
-          if (xx < 0 || xx >= W) continue;
-          const float* p = in + (((size_t)b * H + yy) * W + xx) * ldi;
-          a1 = fmaf(p[c], w1[ky * 3 + kx], a1);
-          a2 = fmaf(p[C + c], w2[ky * 3 + kx], a2);
+        for (int j = 0; j < 6; ++j) {
+          const int xx = x + j - 1;
+          const float m = (yok && xx >= 0 && xx < W) ? 1.f : 0.f;
+          const float* p = rowp + (size_t)min(max(xx, 0), W - 1) * ldi;
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh) v[hh][ky][j] = p[hh * C] * m;
         }
       }
-      float g = a1 * a2;
-      out[((size_t)b * R + r) * ldo + c] = g;
-      s += g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < np) {
+          float a[NH];
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh) {
+            a[hh] = bs[hh];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) a[hh] = fmaf(v[hh][ky][j + kx], wt[hh][ky * 3 + kx], a[hh]);
+          }
+          const float g = GATE ? a[0] * a[NH - 1] : ffsr_act(a[0], act, 0.f);
+          if (live) outb[(size_t)(r + j) * ldo] = g;
+          s += g;
+        }
+      }
+    } else {             // the trip crosses a row end: pixel by pixel
+      for (int j = 0; j < np; ++j) {
+        const int rr = r + j, y2 = rr / W, x2 = rr - y2 * W;
+        float a[NH];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) a[hh] = bs[hh];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = y2 + ky - 1;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x2 + kx - 1;
+            const float m = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1.f : 0.f;
+            const float* p = inb + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * ldi;
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) a[hh] = fmaf(p[hh * C] * m, wt[hh][ky * 3 + kx], a[hh]);
+          }
+        }
+        const float g = GATE ? a[0] * a[NH - 1] : ffsr_act(a[0], act, 0.f);
+        if (live) outb[(size_t)rr * ldo] = g;
+        s += g;
+      }
     }
   }
-  red[pl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (pl == 0 && c < C)
-    part[((size_t)b * nchunk + chunk) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (GATE) {
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && live)
+      part[((size_t)b * nchunk + chunk) * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------- resamplers
@@ -513,7 +595,19 @@ extern "C" int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* g
   }
   unsigned short* oh = (unsigned short*)out_hi;
   unsigned short* ol = (unsigned short*)out_lo;
-  const dim3 grid((M + 7) / 8), block(256);
+  const dim3 block(256);
+  dim3 grid((M + 7) / 8);
+  if (C <= 128) {   // narrow rows: 8 / 16 lanes per row
+    const int lpr = C <= 64 ? 8 : 16;
+    grid = dim3((M + 256 / lpr - 1) / (256 / lpr));
+    if (lpr == 8)
+      hipLaunchKernelGGL((layernorm_v8_kernel<1, 8>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
+                         ldr1, res2, ldr2, M, C);
+    else
+      hipLaunchKernelGGL((layernorm_v8_kernel<1, 16>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
+                         ldr1, res2, ldr2, M, C);
+    return ffsr_launch_status();
+  }
 #define FFSR_LN(NP)                                                                                                      \
   hipLaunchKernelGGL(layernorm_v8_kernel<NP>, grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1, \
                      ldr1, res2, ldr2, M, C)
@@ -579,7 +673,7 @@ extern "C" int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part
                                 void* stream) {
   FFSR_CHECK(x && out && part && B > 0 && R > 0 && C > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(256), 0, ST, part, out, B, C, nchunk, 1.0f / (float)R);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, out, B, C, nchunk, 1.0f / (float)R);
   return ffsr_launch_status();
 }
 
@@ -587,6 +681,13 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
                                  int H, int W, int C, int KH, int KW, int pad_h, int pad_w, int act, void* stream) {
   FFSR_CHECK(in && w && out && B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0);
   long long pix = (long long)B * H * W;
+  if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && pix >= 4096 && B <= 65535) {   // sliding-window kernel
+    const long long per_img = (long long)H * W;
+    const int nchunk = (int)(per_img / 256 < 1 ? 1 : (per_img / 256 > 8192 ? 8192 : per_img / 256));
+    hipLaunchKernelGGL(dw3x3_run_kernel<false>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo,
+                       nullptr, H, W, C, nchunk, act);
+    return ffsr_launch_status();
+  }
   bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out) && al16(w);
   if (v4)
     hipLaunchKernelGGL(dwconv_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W,
@@ -600,9 +701,9 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
 extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
                                         float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream) {
   FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
-  hipLaunchKernelGGL(dw3x3_gate_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part, H,
-                     W, C, nchunk);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(256), 0, ST, part, pooled, B, C, nchunk,
+  hipLaunchKernelGGL(dw3x3_run_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
+                     H, W, C, nchunk, 0);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, pooled, B, C, nchunk,
                      1.0f / (float)(H * W));
   return ffsr_launch_status();
 }

@@ -43,10 +43,14 @@ class Engine:
             self.mamba = MambaIR(weights["mamba"], self.device)
             self.fusion = FusionNet(weights["fusion"], self.device, scale)
             self.concurrent_experts = os.environ.get("FFSR_CONCURRENT_EXPERTS", "1") != "0"
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(4)]
+            # two "lanes" (a main stream + four expert streams each): consecutive images may be submitted to alternate
+            # lanes so that the latency-bound kernels of one image fill the gaps of the other (process(..., lane=i % 2))
+            self._lanes = [(torch.cuda.Stream(self.device), [torch.cuda.Stream(self.device) for _ in range(4)])
+                           for _ in range(2)]
+            self._streams = self._lanes[0][1]
 
     # -------------------------------------------------------------------------------------- experts
-    def run_experts(self, lr):
+    def run_experts(self, lr, streams=None):
         """lr [B,h,w,3] float map -> (imgs, feats) as io._process_image builds them (io.py:224-278).
         The four experts are independent: each runs on its own HIP stream so their launch tails and small kernels
         overlap; the caller's stream waits for all four before the fusion starts."""
@@ -75,21 +79,37 @@ class Engine:
         main = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(main)
-        for job, stream in zip(jobs, self._streams):
+        streams = streams or self._streams
+        for job, stream in zip(jobs, streams):
             stream.wait_event(ready)
             with torch.cuda.stream(stream):
                 job()
-        for stream in self._streams:
+        for stream in streams:
             main.wait_stream(stream)
         for t in list(imgs.values()) + list(feats.values()) + [lp]:
             t.record_stream(main)
         return imgs, feats
 
-    def process(self, lr):
-        """lr [B,h,w,3] float map in [0,1] -> SR map [B,4h,4w,3] in [0,1]."""
+    def process(self, lr, lane=None):
+        """lr [B,h,w,3] float map in [0,1] -> SR map [B,4h,4w,3] in [0,1].
+        lane None: runs on the caller's current stream.  lane 0 / 1: runs asynchronously on that lane's own streams
+        (the caller's stream is only waited for at the start); the caller must ``join()`` before reading the result."""
         with torch.cuda.device(self.device):
-            imgs, feats = self.run_experts(lr)
-            return self.fusion(lr, imgs, feats)
+            if lane is None:
+                imgs, feats = self.run_experts(lr)
+                return self.fusion(lr, imgs, feats)
+            main, streams = self._lanes[lane]
+            main.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(main):
+                lr.record_stream(main)
+                imgs, feats = self.run_experts(lr, streams)
+                return self.fusion(lr, imgs, feats)
+
+    def join(self):
+        """The caller's current stream waits for both lanes."""
+        cur = torch.cuda.current_stream(self.device)
+        for main, _ in self._lanes:
+            cur.wait_stream(main)
 
     def process_tta(self, lr):
         """8x geometric self-ensemble: mean over {hflip} x {rot90^k} of the de-transformed outputs,

@@ -401,7 +401,7 @@ def mul_add(a, b, *, row_broadcast=False, c=None, alpha=1.0, gamma=1.0, out=None
 
 
 def _nchunk(R: int) -> int:
-    return max(1, min(256, R // 256))
+    return max(1, min(2048, R // 64))
 
 
 def _nchunk_gate(R: int) -> int:

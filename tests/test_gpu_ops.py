@@ -111,9 +111,10 @@ def test_elementwise(ops, E):
     close(ops.colmean(E.nchw_to_map(big, DEV)).cpu(), big.mean((2, 3)), 1e-5, "colmean big")
 
 
-@pytest.mark.parametrize("C,kh,kw", [(360, 3, 3), (64, 5, 5), (128, 1, 21), (64, 21, 1), (3, 5, 5)])
-def test_dwconv(ops, E, C, kh, kw):
-    x, w, b = rnd(2, C, 19, 23, seed=1), rnd(C, 1, kh, kw, seed=2), rnd(C, seed=3)
+@pytest.mark.parametrize("C,kh,kw,H,W", [(360, 3, 3, 19, 23), (360, 3, 3, 70, 91), (100, 3, 3, 64, 64), (64, 5, 5, 19, 23),
+                                         (128, 1, 21, 19, 23), (64, 21, 1, 19, 23), (3, 5, 5, 19, 23)])
+def test_dwconv(ops, E, C, kh, kw, H, W):
+    x, w, b = rnd(2, C, H, W, seed=1), rnd(C, 1, kh, kw, seed=2), rnd(C, seed=3)
     want = F.silu(F.conv2d(x, w, b, padding=(kh // 2, kw // 2), groups=C))
     got = ops.dwconv2d(E.nchw_to_map(x, DEV), ops.pack_dwconv(w, b, DEV), act=5)
     close(E.map_to_nchw(got), want, 1e-5, "dwconv")

@@ -108,7 +108,8 @@ def test_chained_planes_gemms_match_f32_chain(ops, E):
     close(got.cpu(), want, 2e-4, "mlp chain")
 
 
-@pytest.mark.parametrize("M,C,ldx", [(1000, 180, 308), (37, 64, 64), (513, 308, 308), (100, 1024, 1024), (64, 360, 720)])
+@pytest.mark.parametrize("M,C,ldx", [(1000, 180, 308), (37, 64, 64), (1001, 128, 128), (513, 308, 308), (100, 1024, 1024), (64, 360, 720),
+                                     (333, 32, 64)])
 def test_layernorm_plane_output(ops, M, C, ldx):
     """LayerNorm (+ residuals) emitting fp32 and planes: the planes are exactly split(fp32 result)."""
     xw = rnd(M, ldx, seed=1)
