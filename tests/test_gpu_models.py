@@ -163,6 +163,40 @@ def test_full_depth_experts_and_fusion_vs_oracle_64x64(mode):
     assert final < TOL, (mode, final)
 
 
+def test_full_size_340x510_fast_mode_agrees_with_exact_mode():
+    """BASELINE's full size (340x510 LR -> 1360x2040, full-depth experts): the CPU oracle would need minutes here, so
+    parity at this size is pinned through a size-independent property -- the default arithmetic (split-bf16 MFMA GEMMs
+    on bf16 hi/lo planes, split-bf16 window attention) must agree with the EXACT mode (f32-MFMA GEMMs and attention:
+    fmaf chains, the arithmetic class of the reference's CPU path, itself oracle-checked at 64x64 above) to north_star's
+    1e-3 max-abs; plus determinism (two runs bit-identical) and the [0, 1] output range."""
+    import math
+    W, E, ops = mod("weights"), mod("engine"), mod("ops")
+    weights = W.random_weights(seed=50)
+    lr = lr_image(21, 1, 340, 510)
+    outs = {}
+    for mode in ("bf16x3", "f32"):
+        ops.set_gemm_mode(mode)
+        try:
+            eng = E.Engine(weights, DEV)
+            lrm = E.nchw_to_map(lr, DEV)
+            out = eng.process(lrm)
+            if mode == "bf16x3":
+                again = eng.process(lrm)
+                assert torch.equal(out, again), "the default path is not deterministic"
+            outs[mode] = out[..., :3].float().cpu()
+            del eng
+            torch.cuda.empty_cache()
+        finally:
+            ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
+    a, b = outs["bf16x3"], outs["f32"]
+    assert a.shape == (1, 1360, 2040, 3)
+    assert a.min().item() >= 0.0 and a.max().item() <= 1.0 and torch.isfinite(a).all()
+    diff = err(a, b)
+    mse = ((a - b) ** 2).mean().item()
+    print(f"340x510: max |fast - exact| = {diff:.3e}, PSNR(fast, exact) = {10 * math.log10(1.0 / max(mse, 1e-20)):.1f} dB")
+    assert diff < TOL, diff
+
+
 def test_device_metrics_match_reference_formulas():
     """BT.601-Y PSNR / SSIM with 4 px crop (metrics.py:30-186), device vs CPU oracle."""
     from ffsr_oracle import metrics as om
