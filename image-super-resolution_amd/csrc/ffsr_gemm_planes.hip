@@ -8,8 +8,13 @@
 //   A[m, (tap, c)] = in[pixel(m) + tap offset, c]   (zero page for out-of-image taps / rows >= M)
 //
 // Tile: BM x BN (BM = 128 / 256, BN = 64 / 128 / 192 / 256), BM/64 x 2 waves, wave tile 64 x BN/2 (2 x TN MFMA tiles of
-// 32x32).  Measured and rejected: delaying the second-resident workgroups by half a tile time (de-phasing the load and
-// store phases of the two workgroups of a CU) changes nothing.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
+// 32x32).  Measured and rejected (MI355X, cold caches, tools/planes_bench.py COLD=1): (a) delaying the second-resident
+// workgroups by half a tile time (de-phasing the load and store phases of the two workgroups of a CU): no change;
+// (b) a persistent role-split kernel -- one 512-thread workgroup per CU walking a tile list, 4 loader waves running
+// the LDS-DMA stream 2-3 K steps ahead across tile boundaries, 4 consumer waves doing fragments + MFMA + epilogue:
+// correct, 0-10 % SLOWER on every shape (K = 180 token GEMMs and 3x3 convs alike).  With cold caches the K <= 360 token
+// GEMMs already run at 57-84 % of what the chip's plain streaming kernels reach on the same bytes (~4 TB/s): what is
+// left for them is fewer bytes (fusion), not a different pipeline.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
 // ~16 B/clk/CU), not the matrix pipe, is what bounds the 128-row tile on long-K shapes.
 // LDS image of one stage: A_hi | A_lo | B_hi | B_lo, rows of 64 B (32 bf16), no padding: one LDS-DMA instruction
 // writes 16 rows x 64 B lane-linear.  Bank conflicts are removed on the SOURCE side: the 16-byte chunk c of row r is
@@ -95,6 +100,106 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
   else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// ---- epilogue of one 128 x BN tile (shared by the kernels below).  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).  Per 32x32 tile: bias / activation / column scale in the accumulator
+// layout (column = lane), transpose through the 32 x 36-float scratch T of this wave, then lane = (row 16*pass + lane/4,
+// columns 8*(lane&3) .. +7): fp32 output as 16-byte stores and / or bf16 hi / lo planes as 16-byte stores.
+template <int TM, int TN, bool GELU>
+__device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&acc)[TM][TN], float* T, int m0, int n0, int wrow,
+                                                int wcol, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int erow = lane >> 2, ecol = (lane & 3) * 8;
+  const int ldp = p.ldp;
+  // wave-uniform: may the 8-column groups use 16-byte accesses?
+  const bool vec_ok = (!p.out || ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0)) &&
+                      (!p.res || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)) &&
+                      (!p.rvec || (reinterpret_cast<uintptr_t>(p.rvec) & 15) == 0);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int ncol = n0 + wcol + jn * 32;          // first column of this tile
+    if (ncol >= p.N && ncol >= ldp) continue;      // wave-uniform: nothing to write
+    const int nc = min(ncol + r, p.N - 1);
+    const float bia = p.bias ? p.bias[nc] : 0.f;
+    const float cs_ = (p.cvec ? p.cvec[nc] : 1.f) * p.cscale;
+    const int nn = ncol + ecol;                    // first of this lane's 8 output columns
+    const bool fast = vec_ok && nn + 8 <= p.N;
+    floatx4 rs0 = {p.rscale, p.rscale, p.rscale, p.rscale}, rs1 = rs0;
+    if (p.res && p.rvec && fast) {
+      rs0 *= *reinterpret_cast<const floatx4*>(p.rvec + nn);
+      rs1 *= *reinterpret_cast<const floatx4*>(p.rvec + nn + 4);
+    }
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+      floatx16 v = acc[im][jn];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bia;
+      if constexpr (GELU) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = v[e] * cs_;
+      // (the same wave wrote and reads T: LDS operations of one wave complete in order)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 16 + erow;
+        const int m = m0 + wrow + im * 32 + row;
+        if (m >= p.M) continue;
+        const float* tp = T + row * 36 + ecol;
+        if (fast) {
+          floatx4 o0 = *reinterpret_cast<const floatx4*>(tp), o1 = *reinterpret_cast<const floatx4*>(tp + 4);
+          if (p.res) {
+            const float* rp = p.res + (size_t)m * p.ldr + nn;
+            o0 += *reinterpret_cast<const floatx4*>(rp) * rs0;
+            o1 += *reinterpret_cast<const floatx4*>(rp + 4) * rs1;
+          }
+          if (p.out) {
+            float* op = p.out + (size_t)m * p.ldo + nn;
+            *reinterpret_cast<floatx4*>(op) = o0;
+            *reinterpret_cast<floatx4*>(op + 4) = o1;
+          }
+          if (p.o_hi) {
+            unsigned hh[4], ll[4];
+            split2(o0[0], o0[1], hh[0], ll[0]);
+            split2(o0[2], o0[3], hh[1], ll[1]);
+            split2(o1[0], o1[1], hh[2], ll[2]);
+            split2(o1[2], o1[3], hh[3], ll[3]);
+            const uintx4 hi4 = {hh[0], hh[1], hh[2], hh[3]}, lo4 = {ll[0], ll[1], ll[2], ll[3]};
+            *reinterpret_cast<uintx4*>(p.o_hi + (size_t)m * ldp + nn) = hi4;
+            *reinterpret_cast<uintx4*>(p.o_lo + (size_t)m * ldp + nn) = lo4;
+          }
+        } else {
+          // edge / unaligned columns: one pair at a time (rare: N % 8 != 0 tails, odd strides)
+#pragma nounroll
+          for (int c = 0; c < 8; c += 2) {
+            float x[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const int n = nn + c + d;
+              float o = 0.f;
+              if (n < p.N) {
+                o = tp[c + d];
+                if (p.res) o += p.res[(size_t)m * p.ldr + n] * (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
+                if (p.out) p.out[(size_t)m * p.ldo + n] = o;
+              }
+              x[d] = o;
+            }
+            if (p.o_hi && nn + c < ldp) {   // ldp is even: pairs are whole; columns >= N are written as zeros
+              unsigned hh, ll;
+              split2(x[0], x[1], hh, ll);
+              *reinterpret_cast<unsigned*>(p.o_hi + (size_t)m * ldp + nn + c) = hh;
+              *reinterpret_cast<unsigned*>(p.o_lo + (size_t)m * ldp + nn + c) = ll;
+            }
+          }
+        }
+      }
+    }
+  }
 }
 
 // GELU: exact-erf GELU epilogue; otherwise the epilogue activation is v > 0 ? v : v * slope (none: slope 1, ReLU: 0).
@@ -275,100 +380,8 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
   wait_vmcnt<0>();                // zero-page fetches of the last steps
   __builtin_amdgcn_s_barrier();   // all fragment reads done: the staging LDS becomes the transpose scratch
 
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
-  // Per 32x32 tile: bias / activation / column scale in the accumulator layout (column = lane), transpose through a
-  // 32 x 36-float scratch of this wave, then lane = (row 16*pass + lane/4, columns 8*(lane&3) .. +7).
-  float* T = reinterpret_cast<float*>(smem) + wave * (32 * 36);
-  const int erow = lane >> 2, ecol = (lane & 3) * 8;
-  const int ldp = p.ldp;
-  // wave-uniform: may the 8-column groups use 16-byte accesses?
-  const bool vec_ok = (!p.out || ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0)) &&
-                      (!p.res || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)) &&
-                      (!p.rvec || (reinterpret_cast<uintptr_t>(p.rvec) & 15) == 0);
-#pragma unroll
-  for (int jn = 0; jn < TN; ++jn) {
-    const int ncol = n0 + wcol + jn * 32;          // first column of this tile
-    if (ncol >= p.N && ncol >= ldp) continue;      // wave-uniform: nothing to write
-    const int nc = min(ncol + r, p.N - 1);
-    const float bia = p.bias ? p.bias[nc] : 0.f;
-    const float cs_ = (p.cvec ? p.cvec[nc] : 1.f) * p.cscale;
-    const int nn = ncol + ecol;                    // first of this lane's 8 output columns
-    const bool fast = vec_ok && nn + 8 <= p.N;
-    floatx4 rs0 = {p.rscale, p.rscale, p.rscale, p.rscale}, rs1 = rs0;
-    if (p.res && p.rvec && fast) {
-      rs0 *= *reinterpret_cast<const floatx4*>(p.rvec + nn);
-      rs1 *= *reinterpret_cast<const floatx4*>(p.rvec + nn + 4);
-    }
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-      floatx16 v = acc[im][jn];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += bia;
-      if constexpr (GELU) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = v[e] * cs_;
-      // (the same wave wrote and reads T: LDS operations of one wave complete in order)
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 16 + erow;
-        const int m = m0 + wrow + im * 32 + row;
-        if (m >= p.M) continue;
-        const float* tp = T + row * 36 + ecol;
-        if (fast) {
-          floatx4 o0 = *reinterpret_cast<const floatx4*>(tp), o1 = *reinterpret_cast<const floatx4*>(tp + 4);
-          if (p.res) {
-            const float* rp = p.res + (size_t)m * p.ldr + nn;
-            o0 += *reinterpret_cast<const floatx4*>(rp) * rs0;
-            o1 += *reinterpret_cast<const floatx4*>(rp + 4) * rs1;
-          }
-          if (p.out) {
-            float* op = p.out + (size_t)m * p.ldo + nn;
-            *reinterpret_cast<floatx4*>(op) = o0;
-            *reinterpret_cast<floatx4*>(op + 4) = o1;
-          }
-          if (p.o_hi) {
-            unsigned hh[4], ll[4];
-            split2(o0[0], o0[1], hh[0], ll[0]);
-            split2(o0[2], o0[3], hh[1], ll[1]);
-            split2(o1[0], o1[1], hh[2], ll[2]);
-            split2(o1[2], o1[3], hh[3], ll[3]);
-            const uintx4 hi4 = {hh[0], hh[1], hh[2], hh[3]}, lo4 = {ll[0], ll[1], ll[2], ll[3]};
-            *reinterpret_cast<uintx4*>(p.o_hi + (size_t)m * ldp + nn) = hi4;
-            *reinterpret_cast<uintx4*>(p.o_lo + (size_t)m * ldp + nn) = lo4;
-          }
-        } else {
-          // edge / unaligned columns: one pair at a time (rare: N % 8 != 0 tails, odd strides)
-#pragma nounroll
-          for (int c = 0; c < 8; c += 2) {
-            float x[2];
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-              const int n = nn + c + d;
-              float o = 0.f;
-              if (n < p.N) {
-                o = tp[c + d];
-                if (p.res) o += p.res[(size_t)m * p.ldr + n] * (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
-                if (p.out) p.out[(size_t)m * p.ldo + n] = o;
-              }
-              x[d] = o;
-            }
-            if (p.o_hi && nn + c < ldp) {   // ldp is even: pairs are whole; columns >= N are written as zeros
-              unsigned hh, ll;
-              split2(x[0], x[1], hh, ll);
-              *reinterpret_cast<unsigned*>(p.o_hi + (size_t)m * ldp + nn + c) = hh;
-              *reinterpret_cast<unsigned*>(p.o_lo + (size_t)m * ldp + nn + c) = ll;
-            }
-          }
-        }
-      }
-    }
-  }
+  // ---- epilogue (the staging LDS is idle now: it serves as the transpose scratch)
+  planes_epilogue<TM, TN, GELU>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), m0, n0, wrow, wcol, lane);
   FFSR_STAMP(5);                  // epilogue done (stores issued)
 }
 
