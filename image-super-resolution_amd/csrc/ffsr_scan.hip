@@ -54,7 +54,7 @@ __device__ __forceinline__ float softplus_f(float x) {
 // Steps are processed in groups of G: the group's u values (registers) and projection rows (LDS, wave-uniform reads)
 // are fetched one group ahead, so the recurrence never waits on HBM latency.
 template <int R, bool EMIT>
-__global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs p) {
+__global__ __launch_bounds__(64, 4) void scan_chunk_kernel(ScanArgs p) {
   constexpr int G = 8, XW = R + 2 * NS, XN = (G * XW + 63) / 64;
   __shared__ float xs[2][G * XW];
   const int lane = threadIdx.x;
