@@ -151,32 +151,62 @@ __global__ __launch_bounds__(64, 4) void scan_chunk_kernel(ScanArgs p) {
   }
 }
 
-// hstate[c] <- state entering chunk c
-__global__ void scan_carry_kernel(float* __restrict__ hstate, const float* __restrict__ decay, int groups, int nchunk,
-                                  int per) {
-  // groups = B*4, per = Dm*NS
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= groups * per) return;
-  int g = idx / per, i = idx - g * per;
-  float hin = 0.f;
+// hstate[c] <- state entering chunk c.  The carry over chunks is the affine recurrence h' = decay * h + local, one
+// independent chain per (batch, direction, channel, state) = only B*4*Dm*16 chains: a thread per chain walks ~512
+// chunks with dependent loads on a quarter of the chip.  Here a 1024-thread block covers 64 chains x SEG = 16 segments
+// of the chunk range: every thread composes the affine map of its segment (h -> P h + Q), the 16 maps are combined
+// through LDS, and the segment is walked a second time from its true incoming state.  Lanes run along the chains, so
+// every access is a contiguous 256-byte row segment.
+constexpr int CARRY_SEG = 16;
+__global__ __launch_bounds__(64 * CARRY_SEG) void scan_carry_kernel(float* __restrict__ hstate, const float* __restrict__ decay,
+                                                                    int nchunk, int per) {
+  __shared__ float Ps[CARRY_SEG][64], Qs[CARRY_SEG][64];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane, g = blockIdx.y;
+  const bool live = i < per;
+  const int ii = live ? i : per - 1;
+  const int cps = (nchunk + CARRY_SEG - 1) / CARRY_SEG;
+  const int c0 = seg * cps, c1 = min(nchunk, c0 + cps);
+  const size_t base = (size_t)g * nchunk * per + ii;
+  float P = 1.f, Q = 0.f;
   constexpr int U = 8;  // loads of U chunks are issued together (they do not depend on the recurrence)
-  for (int c0 = 0; c0 < nchunk; c0 += U) {
+  for (int cc = c0; cc < c1; cc += U) {
     float hl[U], dc[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const size_t o = ((size_t)g * nchunk + min(c0 + j, nchunk - 1)) * per + i;
+      const size_t o = base + (size_t)min(cc + j, nchunk - 1) * per;
       hl[j] = hstate[o];
       dc[j] = decay[o];
     }
 #pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (cc + j < c1) {
+        P *= dc[j];
+        Q = fmaf(dc[j], Q, hl[j]);
+      }
+  }
+  Ps[seg][lane] = P;
+  Qs[seg][lane] = Q;
+  __syncthreads();
+  float hin = 0.f;
+  for (int sgm = 0; sgm < seg; ++sgm) hin = fmaf(Ps[sgm][lane], hin, Qs[sgm][lane]);
+  for (int cc = c0; cc < c1; cc += U) {
+    float hl[U], dc[U];
+#pragma unroll
     for (int j = 0; j < U; ++j) {
-      if (c0 + j < nchunk) {
-        hstate[((size_t)g * nchunk + c0 + j) * per + i] = hin;
+      const size_t o = base + (size_t)min(cc + j, nchunk - 1) * per;
+      hl[j] = hstate[o];
+      dc[j] = decay[o];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (cc + j < c1) {
+        if (live) hstate[base + (size_t)(cc + j) * per] = hin;
         hin = fmaf(dc[j], hin, hl[j]);
       }
-    }
   }
 }
+
 
 // y = LayerNorm_Dm(y0 + y1 + y2 + y3) * silu(z)        (SS2D.forward, mambair_arch.py:380-384)
 __global__ __launch_bounds__(256) void mamba_norm_gate_kernel(const float* __restrict__ y, size_t ystride, int ldy,
@@ -290,9 +320,8 @@ template <int R>
 int run_scan(const ScanArgs& a, hipStream_t st) {
   dim3 grid((a.Dm + 63) / 64, a.nchunk, 4 * a.B);
   hipLaunchKernelGGL((scan_chunk_kernel<R, false>), grid, dim3(64), 0, st, a);
-  int tot = a.B * 4 * a.Dm * NS;
-  hipLaunchKernelGGL(scan_carry_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, a.hstate, a.decay, a.B * 4, a.nchunk,
-                     a.Dm * NS);
+  hipLaunchKernelGGL(scan_carry_kernel, dim3((a.Dm * NS + 63) / 64, a.B * 4), dim3(64 * CARRY_SEG), 0, st, a.hstate, a.decay,
+                     a.nchunk, a.Dm * NS);
   hipLaunchKernelGGL((scan_chunk_kernel<R, true>), grid, dim3(64), 0, st, a);
   return ffsr_launch_status();
 }
