@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void layernorm_v8_kernel(const float* __restri
                                                            int ldo, unsigned short* __restrict__ ohi,
                                                            unsigned short* __restrict__ olo, int ldp,
                                                            const float* __restrict__ r1, int ldr1,
-                                                           const float* __restrict__ r2, int ldr2, int M, int C) {
+                                                           const float* __restrict__ r2, int ldr2,
+                                                           const float* __restrict__ r2vec, int rpb, int M, int C) {
   static_assert(LPR == 32 || NPASS == 1, "narrow rows are single pass");
   const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
@@ -116,7 +117,11 @@ __global__ __launch_bounds__(256) void layernorm_v8_kernel(const float* __restri
       if (c < C) {
         t = (v[p][hh] - mean) * rstd * *reinterpret_cast<const floatx4*>(g + c) + *reinterpret_cast<const floatx4*>(b + c);
         if (r1) t += *reinterpret_cast<const floatx4*>(r1 + (size_t)row * ldr1 + c);
-        if (r2) t += *reinterpret_cast<const floatx4*>(r2 + (size_t)row * ldr2 + c);
+        if (r2) {
+          floatx4 t2 = *reinterpret_cast<const floatx4*>(r2 + (size_t)row * ldr2 + c);
+          if (r2vec) t2 *= *reinterpret_cast<const floatx4*>(r2vec + (size_t)(row / rpb) * C + c);   // per-(batch, channel) scale
+          t += t2;
+        }
         if (out) *reinterpret_cast<floatx4*>(out + (size_t)row * ldo + c) = t;
       }
 #pragma unroll
@@ -581,14 +586,18 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps,
                                          float* out, int ldo, void* out_hi, void* out_lo, int ldp, const float* res1,
-                                         int ldr1, const float* res2, int ldr2, int M, int C, void* stream) {
+                                         int ldr1, const float* res2, int ldr2, const float* res2_vec, int rows_per_batch,
+                                         int M, int C, void* stream) {
+  const float* r2vec = res2_vec;
+  const int rpb = rows_per_batch > 0 ? rows_per_batch : M;
+  FFSR_CHECK(!r2vec || (res2 && al16(r2vec)));
   FFSR_CHECK(x && gamma && beta && (out || (out_hi && out_lo)) && M > 0 && C > 0 && C <= 1024 && ldx >= C);
   FFSR_CHECK(!out || ldo >= C);
   FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= C && ldp < C + 32 && al16(out_hi) && al16(out_lo)));
   const bool v8 = (C % 4 == 0) && (ldx % 4 == 0) && al16(x) && al16(gamma) && al16(beta) && (!out || (ldo % 4 == 0 && al16(out))) &&
                   (!res1 || (ldr1 % 4 == 0 && al16(res1))) && (!res2 || (ldr2 % 4 == 0 && al16(res2)));
   if (!v8) {
-    FFSR_CHECK(out && !out_hi);   // the scalar fallback writes fp32 only
+    FFSR_CHECK(out && !out_hi && !r2vec);   // the scalar fallback writes fp32 only and has no scaled residual
     hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, ldx, gamma, beta, eps, out, ldo, res1,
                        ldr1, res2, ldr2, M, C);
     return ffsr_launch_status();
@@ -602,15 +611,15 @@ extern "C" int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* g
     grid = dim3((M + 256 / lpr - 1) / (256 / lpr));
     if (lpr == 8)
       hipLaunchKernelGGL((layernorm_v8_kernel<1, 8>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
-                         ldr1, res2, ldr2, M, C);
+                         ldr1, res2, ldr2, r2vec, rpb, M, C);
     else
       hipLaunchKernelGGL((layernorm_v8_kernel<1, 16>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
-                         ldr1, res2, ldr2, M, C);
+                         ldr1, res2, ldr2, r2vec, rpb, M, C);
     return ffsr_launch_status();
   }
 #define FFSR_LN(NP)                                                                                                      \
   hipLaunchKernelGGL(layernorm_v8_kernel<NP>, grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1, \
-                     ldr1, res2, ldr2, M, C)
+                     ldr1, res2, ldr2, r2vec, rpb, M, C)
   if (C <= 256) FFSR_LN(1);
   else if (C <= 512) FFSR_LN(2);
   else if (C <= 768) FFSR_LN(3);
@@ -623,8 +632,8 @@ extern "C" int ffsr_layernorm_f32(const float* x, int ldx, const float* gamma, c
                                   int ldo, const float* res1, int ldr1, const float* res2, int ldr2, int M, int C,
                                   void* stream) {
   FFSR_CHECK(out);
-  return ffsr_layernorm_planes_f32(x, ldx, gamma, beta, eps, out, ldo, nullptr, nullptr, 0, res1, ldr1, res2, ldr2, M, C,
-                                   stream);
+  return ffsr_layernorm_planes_f32(x, ldx, gamma, beta, eps, out, ldo, nullptr, nullptr, 0, res1, ldr1, res2, ldr2, nullptr, 0,
+                                   M, C, stream);
 }
 
 extern "C" int ffsr_unary_f32(const float* x, int ldx, float* out, int ldo, long long M, int C, int act, float slope,

@@ -81,12 +81,12 @@ class _Block:
         ops.grl_stripe_attn(qkv, 3 * C // 2, anchor, self.b1, self.b2, self.l1, self.l2, cat, C // 2, B, H, W, heads, hd)
         a = ops.linear(cat, self.proj)
         c2, att = self.cab(xm)
-        base = ops.scale_add(xm, c2, bvec=att)                             # x + CAB(x)
+        # y = x + LN(attn(x)) + CAB(x): the channel-attention scaling of CAB (c2 * att[batch]) rides in the LN kernel
         if not pl:
-            y = ops.layernorm(a, *self.n1, res1=tokens(base))              # + LN(attn(x))
+            y = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W)
             m = ops.linear(ops.linear(y, self.fc1, act=ACT_GELU), self.fc2)
             return ops.layernorm(m, *self.n2, res1=y), None
-        y, yp = ops.layernorm(a, *self.n1, res1=tokens(base), out_planes=True)
+        y, yp = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W, out_planes=True)
         m = ops.linear(ops.linear(yp, self.fc1, act=ACT_GELU, out_planes=True, want_f32=False), self.fc2)
         return ops.layernorm(m, *self.n2, res1=y, out_planes=True)
 

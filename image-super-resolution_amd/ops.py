@@ -336,8 +336,9 @@ def _like(t: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     return new_map(t.shape[0], t.shape[1], t.shape[2], C or t.shape[3], t.device)
 
 
-def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None, out_planes=None, want_f32=True):
-    """out = LN(x) * gamma + beta (+ res1) (+ res2).  out_planes: True / a Planes -> also emit the result as bf16 hi / lo
+def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None, out_planes=None, want_f32=True, res2_vec=None,
+              rows_per_batch=0):
+    """out = LN(x) * gamma + beta (+ res1) (+ res2 [* res2_vec[batch, :]]).  out_planes: True / a Planes -> also emit the result as bf16 hi / lo
     planes for the planes GEMM (returns (out, planes), or only the planes when want_f32 is False)."""
     _, M, C, ldx = _mat(x)
     if out_planes is True:
@@ -346,14 +347,19 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, res1=None, res2=None, out_plan
         out = _like(x)
     r1 = _mat(res1) if res1 is not None else (None, 0, 0, 0)
     r2 = _mat(res2) if res2 is not None else (None, 0, 0, 0)
-    if out_planes is None:
+    if res2_vec is not None:
+        assert res2 is not None and res2_vec.is_contiguous() and res2_vec.shape[-1] == C and rows_per_batch > 0
+    if out_planes is None and res2_vec is None:
         hip.call("ffsr_layernorm_f32", _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _mat(out)[3],
                  _ptr(r1[0]), r1[3], _ptr(r2[0]), r2[3], M, C, _stream())
         return out
-    assert out_planes.M == M and out_planes.C == C
+    assert out_planes is None or (out_planes.M == M and out_planes.C == C)
     hip.call("ffsr_layernorm_planes_f32", _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(out),
-             0 if out is None else _mat(out)[3], _ptr(out_planes.hi), _ptr(out_planes.lo), out_planes.Cp, _ptr(r1[0]), r1[3],
-             _ptr(r2[0]), r2[3], M, C, _stream())
+             0 if out is None else _mat(out)[3], None if out_planes is None else _ptr(out_planes.hi),
+             None if out_planes is None else _ptr(out_planes.lo), 0 if out_planes is None else out_planes.Cp, _ptr(r1[0]), r1[3],
+             _ptr(r2[0]), r2[3], _ptr(res2_vec), rows_per_batch, M, C, _stream())
+    if out_planes is None:
+        return out
     return (out, out_planes) if out is not None else out_planes
 
 

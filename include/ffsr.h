@@ -77,10 +77,13 @@ int ffsr_layernorm_f32(const float* x, int ldx, const float* gamma, const float*
 
 /* ffsr_layernorm_f32 that can also (or only) emit the result as bf16 hi / lo planes [M, ldp] (ldp = C rounded up to
  * 32, pad columns zero) for ffsr_conv2d_planes: out may be NULL when out_hi / out_lo are given.  Plane output needs
- * the vectorised path (C % 4 == 0, 16-byte aligned rows). */
+ * the vectorised path (C % 4 == 0, 16-byte aligned rows).  res2_vec [B, C] (optional) scales res2 per (batch, channel)
+ * with rows_per_batch rows per batch: out = LN(x) + res1 + res2 * res2_vec[batch] -- GRL's x + LN(attn(x)) + CAB(x)
+ * with the RCAN channel attention of CAB folded in (mixed_attn_block_efficient.py:543-554, mixed_attn_block.py:942-983). */
 int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out,
                               int ldo, void* out_hi, void* out_lo, int ldp, const float* res1, int ldr1,
-                              const float* res2, int ldr2, int M, int C, void* stream);
+                              const float* res2, int ldr2, const float* res2_vec, int rows_per_batch, int M, int C,
+                              void* stream);
 
 /* out = clamp(act(x * pre) * alpha * cscale[n] + beta + cbias[n], lo, hi) (cscale, cbias [C] optional; clamp only if
  * do_clamp).  Covers eval-mode BatchNorm (large_kernel_attention.py:143), mean shifts, clamps, activations. */

@@ -123,3 +123,17 @@ def test_layernorm_plane_output(ops, M, C, ldx):
     assert torch.equal(only.buf, pl.buf)
     plain = ops.layernorm(x, g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV))
     assert torch.equal(plain, out)
+
+
+def test_layernorm_scaled_second_residual(ops):
+    """out = LN(x) + res1 + res2 * vec[batch]: GRL's x + LN(attn) + CAB(x) with the channel attention folded in."""
+    B, R, C = 3, 50, 180
+    x, g, b = rnd(B * R, C, seed=1), rnd(C, seed=2), rnd(C, seed=3)
+    r1, r2, vec = rnd(B * R, C, seed=4), rnd(B * R, C, seed=5), rnd(B, C, seed=6)
+    want = F.layer_norm(x, (C,), g, b, 1e-5) + r1 + (r2.reshape(B, R, C) * vec[:, None, :]).reshape(B * R, C)
+    out, pl = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV), res2_vec=vec.to(DEV),
+                            rows_per_batch=R, out_planes=True)
+    close(out.cpu(), want, 1e-5, "layernorm + scaled residual")
+    assert torch.equal(pl.buf, ops.split_planes(out).buf)
+    plain = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV), res2_vec=vec.to(DEV), rows_per_batch=R)
+    assert torch.equal(plain, out)
