@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=H_LR)
     ap.add_argument("--width", type=int, default=W_LR)
+    ap.add_argument("--graph", action="store_true", help="replay each step from a captured HIP graph (pays on small tiles)")
     ap.add_argument("--lanes", type=int, default=1, help="stream lanes: images in flight per GPU (1 or 2)")
     ap.add_argument("--batch", type=int, default=1, help="images per step per GPU (BASELINE config 3 uses 16 x 64x64)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -114,8 +115,9 @@ def main():
             print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     log(f"engine ready; warm-up x{args.warmup} on {h}x{w} LR")
+    step_fn = eng.process_graphed if args.graph else eng.process
     for i in range(args.warmup):
-        eng.process(lrs[i % len(lrs)])
+        step_fn(lrs[i % len(lrs)])
         torch.cuda.synchronize(device)
         log(f"warm-up step {i} done")
     barrier()
@@ -123,7 +125,8 @@ def main():
     outs = []
     for i in range(args.steps):
         # consecutive steps go to alternate stream lanes (two images in flight); --lanes 1 serialises them
-        outs.append(eng.process(lrs[i % len(lrs)], lane=(i % args.lanes) if args.lanes > 1 else None))
+        outs.append(eng.process_graphed(lrs[i % len(lrs)]) if args.graph else
+                    eng.process(lrs[i % len(lrs)], lane=(i % args.lanes) if args.lanes > 1 else None))
         if len(outs) > 2:
             outs.pop(0)
     eng.join()
@@ -231,6 +234,7 @@ def main():
                 "config": {"workload": f"CompleteEnhancedFusionSR hot path: {w}x{h} LR image per step per GPU "
                                        f"(pad16 -> DRCT-L + GRL-B + NAFNet-w64 + MambaIR -> fusion), batch {args.batch}",
                            "lr_hw": [h, w], "images_per_step_per_gpu": args.batch, "parallelism": f"image-parallel x{world}",
+                           "hip_graph": bool(args.graph),
                            "small_experts": bool(args.small)},
                 "gemm_mode": ops.GEMM_MODE, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -197,6 +197,19 @@ def test_full_size_340x510_fast_mode_agrees_with_exact_mode():
     assert diff < TOL, diff
 
 
+def test_graph_replay_matches_eager():
+    """Engine.process_graphed (one hipGraph launch per image) is bit-identical to the eager launch sequence, also when
+    the captured graph is replayed on a different image of the same shape."""
+    W, E = mod("weights"), mod("engine")
+    eng = E.Engine(W.random_weights(seed=3, small=True), DEV)
+    a, b = E.nchw_to_map(lr_image(1, 1, 32, 48), DEV), E.nchw_to_map(lr_image(2, 1, 32, 48), DEV)
+    want_a, want_b = eng.process(a).clone(), eng.process(b).clone()
+    assert torch.equal(eng.process_graphed(a), want_a)
+    assert torch.equal(eng.process_graphed(b), want_b)
+    assert torch.equal(eng.process_graphed(a), want_a)
+    assert len(eng._graphs) == 1
+
+
 def test_device_metrics_match_reference_formulas():
     """BT.601-Y PSNR / SSIM with 4 px crop (metrics.py:30-186), device vs CPU oracle."""
     from ffsr_oracle import metrics as om
