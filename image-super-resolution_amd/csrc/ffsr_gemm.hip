@@ -259,9 +259,12 @@ struct ConvArgs3 {
 
 template <int BN, bool HAS_AK>
 __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
-  constexpr int BM = 128, WM = 64, WN = BN / 2;
-  constexpr int TM = 2, TN = WN / 32;
-  constexpr int AR = BM / 32, BRW = BN / 64;
+  // BN = 64 / 128: 2 x 2 waves, wave tile 64 x BN/2.  BN = 32 (thin convs, N <= 32: the 3- / 16- / 32-channel heads of the
+  // fusion net at HR resolution): 4 x 1 waves, wave tile 32 x 32 -- half the MFMA work of padding N to 64.
+  constexpr int BM = 128, WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int AR = BM / 32, BRW = (BN + 63) / 64;
   constexpr int RS = 80;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * RS];
   __shared__ int tapoff[32];
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
     }
 #pragma unroll
     for (int j = 0; j < BRW; ++j) {
+      if (BN < 64 && brow >= BN) break;                                          // BN = 32: half the loader threads idle
       const size_t off = (size_t)(n0 + brow + 64 * j) * p.ldw + kt * BK + bseg;   // planes are padded: always valid
       bh_reg[j] = *reinterpret_cast<const floatx4*>(p.whi + off);
       bl_reg[j] = *reinterpret_cast<const floatx4*>(p.wlo + off);
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
     }
 #pragma unroll
     for (int j = 0; j < BRW; ++j) {
+      if (BN < 64 && brow >= BN) break;
       const int o = (brow + 64 * j) * RS + bseg * 2;
       *reinterpret_cast<floatx4*>(Bhi + o) = bh_reg[j];
       *reinterpret_cast<floatx4*>(Blo + o) = bl_reg[j];
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int wrow = (wave >> 1) * WM, wcol = (wave & 1) * WN;
+  const int wrow = (wave / WAVES_N) * WM, wcol = (wave % WAVES_N) * WN;
   const int r = lane & 31, h = lane >> 5;
   const int nk = (p.Ktot + BK - 1) / BK;
 
@@ -552,7 +557,7 @@ extern "C" int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const voi
              ((uintptr_t)zeros & 15) == 0);
   FFSR_CHECK(shuffle == 0 || (shuffle == 2 && (N & 3) == 0));
   FFSR_CHECK(!akscale || (KH * KW == 1 && akrows > 0 && ((uintptr_t)akscale & 15) == 0));
-  FFSR_CHECK(bn == 64 || bn == 128);
+  FFSR_CHECK(bn == 32 || bn == 64 || bn == 128);
   const int Ktot = KH * KW * Cin;
   FFSR_CHECK((ldw & 31) == 0 && ldw >= Ktot && (n_rows_padded % 128) == 0 && n_rows_padded >= N);
   ConvArgs3 a;
@@ -568,5 +573,6 @@ extern "C" int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const voi
   long long M = (long long)B * a.Ho * a.Wo;
   FFSR_CHECK(M < (1ll << 31) && (long long)B * H * W < (1ll << 31));
   a.M = (int)M;
+  if (bn == 32) return launch_v3<32>(a, (hipStream_t)stream);
   return bn == 64 ? launch_v3<64>(a, (hipStream_t)stream) : launch_v3<128>(a, (hipStream_t)stream);
 }

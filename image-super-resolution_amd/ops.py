@@ -282,8 +282,8 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
             assert akscale.shape == (B, cv.Cin) and akscale.is_contiguous()
             akrows = H * W
         if tile_hint == 0 and GEMM_MODE == "bf16x3" and B * Ho * Wo > 64 * 24 and cv.KH * cv.KW <= 32:
-            tile_hint = 64 if cv.N <= 64 or BN128_MIN_N > cv.N else 128
-        if tile_hint in (64, 128):
+            tile_hint = 32 if cv.N <= 32 else (64 if cv.N <= 64 or BN128_MIN_N > cv.N else 128)
+        if tile_hint in (32, 64, 128):
             hip.call("ffsr_conv2d_bf16x3", _ptr(x), _ptr(cv.whi), _ptr(cv.wlo), cv.whi.shape[1], cv.whi.shape[0],
                      _ptr(zero_page(x.device)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec), _ptr(akscale),
                      B, H, W, cv.Cin, ldi, cv.N, ld(out), ldr, cv.KH, cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope),

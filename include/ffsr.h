@@ -45,7 +45,7 @@ int ffsr_conv2d_f32(const float* in, const float* wgt, const float* bias, float*
  * ~1e-5 relative per product).  wgt_hi / wgt_lo: bf16 planes [n_rows_padded, ldw] of the weight matrix, pre-split at
  * pack time (hi = bf16(w), lo = bf16(w - hi)) and zero padded to n_rows_padded % bn == 0 rows and ldw % 32 == 0
  * columns (n_rows_padded % 128 == 0); zeros: >= 64 bytes of zeros (read for padding taps / rows); bn = column tile,
- * 64 or 128. */
+ * 32 (N <= 32), 64 or 128. */
 int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, int ldw, int n_rows_padded,
                        const float* zeros, const float* bias, float* out, const float* res, const float* cvec,
                        const float* rvec, const float* akscale, int B, int H, int W, int Cin, int ldi, int N, int ldo,
