@@ -772,8 +772,8 @@ extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias
       (void)hipFuncSetAttribute((const void*)window_attn_x3_kernel<K, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)ldsx);                                                                           \
     }                                                                                                                 \
-    if (wide) hipLaunchKernelGGL((window_attn_x3_kernel<K, 8>), gridx, dim3(512), ldsx, ST, a);                        \
-    else hipLaunchKernelGGL((window_attn_x3_kernel<K, 4>), gridx, dim3(256), ldsx, ST, a);                             \
+    if (wide) FFSR_LAUNCH((window_attn_x3_kernel<K, 8>), gridx, dim3(512), ldsx, ST, a);                        \
+    else FFSR_LAUNCH((window_attn_x3_kernel<K, 4>), gridx, dim3(256), ldsx, ST, a);                             \
   }
     switch (KS) {
       case 1: LAUNCH_X3(1); break;
@@ -800,7 +800,7 @@ extern "C" int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias
     if (lds > 64 * 1024)                                                                                            \
       (void)hipFuncSetAttribute((const void*)window_attn_kernel<D, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                          \
-    hipLaunchKernelGGL((window_attn_kernel<D, Q>), grid, dim3(256), lds, ST, a);                                     \
+    FFSR_LAUNCH((window_attn_kernel<D, Q>), grid, dim3(256), lds, ST, a);                                     \
   }
   switch (DT * 10 + QT) {
     case 11: LAUNCH_WIN(1, 1); break;
@@ -822,8 +822,8 @@ extern "C" int ffsr_grl_window_attn_f32(const float* qkv, int ldq, int col0, con
   FFSR_CHECK(qkv && biasT && logit && out && B > 0 && H % 8 == 0 && W % 8 == 0 && heads > 0 && shift >= 0 && shift < 8);
   dim3 grid((H / 8) * (W / 8) * B, heads);
   switch (hd) {
-    case 30: hipLaunchKernelGGL(grl_window_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
-    case 10: hipLaunchKernelGGL(grl_window_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
+    case 30: FFSR_LAUNCH(grl_window_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
+    case 10: FFSR_LAUNCH(grl_window_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
     default: return FFSR_EINVAL;
   }
   return ffsr_launch_status();
@@ -835,8 +835,8 @@ extern "C" int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, con
   FFSR_CHECK(qkv && anchor && bias1T && bias2T && logit1 && logit2 && out && B > 0 && H % 8 == 0 && W % 8 == 0 && heads > 0);
   dim3 grid((H / 8) * (W / 8) * B, heads);
   switch (hd) {
-    case 30: hipLaunchKernelGGL(grl_stripe_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
-    case 10: hipLaunchKernelGGL(grl_stripe_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
+    case 30: FFSR_LAUNCH(grl_stripe_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
+    case 10: FFSR_LAUNCH(grl_stripe_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
     default: return FFSR_EINVAL;
   }
   return ffsr_launch_status();
@@ -849,8 +849,8 @@ extern "C" int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo
   long long n = S * T * heads;
   dim3 grid((unsigned)((n + 255) / 256));
   switch (T) {
-    case 9: hipLaunchKernelGGL(pixel_mha_kernel<9>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
-    case 4: hipLaunchKernelGGL(pixel_mha_kernel<4>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
+    case 9: FFSR_LAUNCH(pixel_mha_kernel<9>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
+    case 4: FFSR_LAUNCH(pixel_mha_kernel<4>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
     default: return FFSR_EINVAL;
   }
   return ffsr_launch_status();

@@ -14,6 +14,15 @@
 
 static inline int ffsr_launch_status() { return hipGetLastError() == hipSuccess ? FFSR_OK : FFSR_ELAUNCH; }
 
+// Every kernel launch of the library goes through FFSR_LAUNCH: it first clears the thread's sticky "last error" (the
+// host framework's own event / stream queries leave hipErrorNotReady there), so that ffsr_launch_status() reports the
+// outcome of OUR launch and not a stale code of an unrelated runtime call.
+#define FFSR_LAUNCH(...)              \
+  do {                                \
+    (void)hipGetLastError();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 // activation codes shared by the GEMM/conv epilogue, the depthwise conv and the elementwise kernels
 enum FfsrAct : int {
   FFSR_ACT_NONE = 0,

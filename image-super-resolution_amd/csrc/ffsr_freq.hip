@@ -220,7 +220,7 @@ extern "C" int ffsr_dct_bands_f32(const float* img, int ldi, const float* D, con
                                   float* bands, int ldb, int B, int H, int W, void* stream) {
   FFSR_CHECK(img && D && masks && scale && bands && B > 0 && H >= 8 && W >= 8 && ldb >= 36);
   const int nbh = (H + 7) / 8, nbw = (W + 7) / 8;
-  hipLaunchKernelGGL(dct_bands_kernel, dim3((B * nbh * nbw * 3 + 3) / 4), dim3(256), 0, ST, img, ldi, D, masks, scale, bands,
+  FFSR_LAUNCH(dct_bands_kernel, dim3((B * nbh * nbw * 3 + 3) / 4), dim3(256), 0, ST, img, ldi, D, masks, scale, bands,
                      ldb, B, H, W, nbh, nbw);
   return ffsr_launch_status();
 }
@@ -229,7 +229,7 @@ extern "C" int ffsr_dwt_db4_f32(const float* img, int ldi, const float* lo, cons
                                 void* stream) {
   FFSR_CHECK(img && lo && hi && sub && B > 0 && H >= 8 && W >= 8);
   const int Hd = (H + 6) / 2 + 1, Wd = (W + 6) / 2 + 1;
-  hipLaunchKernelGGL(dwt_kernel, dim3(grid_for((long long)B * Hd * Wd * 3)), dim3(256), 0, ST, img, ldi, lo, hi, sub, B, H, W,
+  FFSR_LAUNCH(dwt_kernel, dim3(grid_for((long long)B * Hd * Wd * 3)), dim3(256), 0, ST, img, ldi, lo, hi, sub, B, H, W,
                      Hd, Wd);
   return ffsr_launch_status();
 }
@@ -244,11 +244,11 @@ extern "C" int ffsr_fft_bands_f32(const float* img, int ldi, const float* twW, c
   float2* Zs = Zr + n;       // [2][B*3*H*Wf]  (lo, hi)
   float2* U = Zs + 2 * n;    // [2][B*3*H*Wf]
   const float norm = 1.0f / sqrtf((float)H * (float)W);
-  hipLaunchKernelGGL(dft_rows_kernel, dim3(grid_for(n)), dim3(256), 0, ST, img, ldi, (const float2*)twW, Zr, B, H, W, Wf);
-  hipLaunchKernelGGL(dft_cols_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST, Zr, (const float2*)twH, mask, Zs, Zs + n, B * 3,
+  FFSR_LAUNCH(dft_rows_kernel, dim3(grid_for(n)), dim3(256), 0, ST, img, ldi, (const float2*)twW, Zr, B, H, W, Wf);
+  FFSR_LAUNCH(dft_cols_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST, Zr, (const float2*)twH, mask, Zs, Zs + n, B * 3,
                      H, Wf, norm);
-  hipLaunchKernelGGL(idft_cols_kernel, dim3(grid_for(2 * n)), dim3(256), 0, ST, Zs, (const float2*)twH, U, 2 * B * 3, H, Wf);
-  hipLaunchKernelGGL(idft_rows_kernel, dim3(grid_for((long long)2 * B * 3 * H * W)), dim3(256), 0, ST, U, (const float2*)twW,
+  FFSR_LAUNCH(idft_cols_kernel, dim3(grid_for(2 * n)), dim3(256), 0, ST, Zs, (const float2*)twH, U, 2 * B * 3, H, Wf);
+  FFSR_LAUNCH(idft_rows_kernel, dim3(grid_for((long long)2 * B * 3 * H * W)), dim3(256), 0, ST, U, (const float2*)twW,
                      scale, bands, ldb, B, H, W, Wf, norm);
   return ffsr_launch_status();
 }

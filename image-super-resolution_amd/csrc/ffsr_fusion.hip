@@ -193,7 +193,7 @@ inline int grid_for(long long n) { return (int)((n + 255) / 256); }
 extern "C" int ffsr_selector_gates_f32(const float* raw, int ldr, const float* diff, int ldd, const float* temperature,
                                        float* gates, int ldg, long long M, void* stream) {
   FFSR_CHECK(raw && diff && temperature && gates && M > 0);
-  hipLaunchKernelGGL(selector_gates_kernel, dim3(grid_for(M)), dim3(256), 0, ST, raw, ldr, diff, ldd, temperature, gates, ldg, M);
+  FFSR_LAUNCH(selector_gates_kernel, dim3(grid_for(M)), dim3(256), 0, ST, raw, ldr, diff, ldd, temperature, gates, ldg, M);
   return ffsr_launch_status();
 }
 
@@ -201,7 +201,7 @@ extern "C" int ffsr_modulate_f32(const float* t_lr, int ldt, const float* w2, co
                                  float* out, int ldo, int B, int h, int w, int Hh, int Wh, void* stream) {
   FFSR_CHECK(t_lr && w2 && b2 && img && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0 && (ldt % 4) == 0 && ldt >= 32);
   FFSR_CHECK(((uintptr_t)t_lr & 15) == 0);
-  hipLaunchKernelGGL(modulate_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, t_lr, ldt, w2, b2, img, ldi, out,
+  FFSR_LAUNCH(modulate_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, t_lr, ldt, w2, b2, img, ldi, out,
                      ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
   return ffsr_launch_status();
 }
@@ -210,7 +210,7 @@ extern "C" int ffsr_fusion_route_f32(const float* enh, int lde, const float* hie
                                      const float* fw, const float* gates, int ldg, const float* diff, int ldd, float* out,
                                      int ldo, int B, int h, int w, int Hh, int Wh, void* stream) {
   FFSR_CHECK(enh && hier && routing && fw && gates && diff && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0 && ldo >= 4);
-  hipLaunchKernelGGL(route_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, enh, lde, hier, ldh, routing, ldr,
+  FFSR_LAUNCH(route_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, enh, lde, hier, ldh, routing, ldr,
                      fw, gates, ldg, diff, ldd, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
   return ffsr_launch_status();
 }
@@ -219,7 +219,7 @@ extern "C" int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, 
                                    const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo,
                                    int B, int h, int w, int Hh, int Wh, void* stream) {
   FFSR_CHECK(sr && edge && gate && strength && lr && rscale && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0);
-  hipLaunchKernelGGL(edge_final_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, sr, lds, edge, lde, gate, ldg,
+  FFSR_LAUNCH(edge_final_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, sr, lds, edge, lde, gate, ldg,
                      strength, lr, ldl, rscale, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
   return ffsr_launch_status();
 }
@@ -227,6 +227,6 @@ extern "C" int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, 
 extern "C" int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12,
                                  int ld, float* out, int ldo, long long M, void* stream) {
   FFSR_CHECK(mu1 && mu2 && e11 && e22 && e12 && out && M > 0 && ld > 0 && ldo > 0);
-  hipLaunchKernelGGL(ssim_map_kernel, dim3(grid_for(M)), dim3(256), 0, ST, mu1, mu2, e11, e22, e12, ld, out, ldo, M);
+  FFSR_LAUNCH(ssim_map_kernel, dim3(grid_for(M)), dim3(256), 0, ST, mu1, mu2, e11, e22, e12, ld, out, ldo, M);
   return ffsr_launch_status();
 }

@@ -479,9 +479,9 @@ template <int BN>
 int launch_v3(const ConvArgs3& a, hipStream_t st) {
   int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
   if (a.akscale)
-    hipLaunchKernelGGL((conv_gemm_bf16x3_v3_kernel<BN, true>), dim3(tiles), dim3(256), 0, st, a);
+    FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, true>), dim3(tiles), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_gemm_bf16x3_v3_kernel<BN, false>), dim3(tiles), dim3(256), 0, st, a);
+    FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, false>), dim3(tiles), dim3(256), 0, st, a);
   return ffsr_launch_status();
 }
 
@@ -489,9 +489,9 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 int launch(const ConvArgs& a, hipStream_t st) {
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (a.akscale)
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, STAGES>), dim3(tiles), dim3(256), 0, st, a);
+    FFSR_LAUNCH((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, STAGES>), dim3(tiles), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, STAGES>), dim3(tiles), dim3(256), 0, st, a);
+    FFSR_LAUNCH((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, STAGES>), dim3(tiles), dim3(256), 0, st, a);
   return ffsr_launch_status();
 }
 

@@ -398,7 +398,7 @@ int launch_planes3(const PlaneArgs& a, hipStream_t st) {
       return FFSR_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>), dim3(tiles), dim3(BM * 2), STAGES * STAGE, st, a);
+  FFSR_LAUNCH((conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>), dim3(tiles), dim3(BM * 2), STAGES * STAGE, st, a);
   return ffsr_launch_status();
 }
 
@@ -515,7 +515,7 @@ extern "C" int ffsr_split_planes(const float* x, int ldx, void* hi, void* lo, in
   FFSR_CHECK(((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0 && ((uintptr_t)x & 15) == 0);
   const long long total = M * (ldp >> 3);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)hi,
+  FFSR_LAUNCH(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)hi,
                      (unsigned short*)lo, ldp, M, C);
   return ffsr_launch_status();
 }

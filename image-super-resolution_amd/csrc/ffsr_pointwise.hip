@@ -598,7 +598,7 @@ extern "C" int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* g
                   (!res1 || (ldr1 % 4 == 0 && al16(res1))) && (!res2 || (ldr2 % 4 == 0 && al16(res2)));
   if (!v8) {
     FFSR_CHECK(out && !out_hi && !r2vec);   // the scalar fallback writes fp32 only and has no scaled residual
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, ldx, gamma, beta, eps, out, ldo, res1,
+    FFSR_LAUNCH(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, ldx, gamma, beta, eps, out, ldo, res1,
                        ldr1, res2, ldr2, M, C);
     return ffsr_launch_status();
   }
@@ -610,15 +610,15 @@ extern "C" int ffsr_layernorm_planes_f32(const float* x, int ldx, const float* g
     const int lpr = C <= 64 ? 8 : 16;
     grid = dim3((M + 256 / lpr - 1) / (256 / lpr));
     if (lpr == 8)
-      hipLaunchKernelGGL((layernorm_v8_kernel<1, 8>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
+      FFSR_LAUNCH((layernorm_v8_kernel<1, 8>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
                          ldr1, res2, ldr2, r2vec, rpb, M, C);
     else
-      hipLaunchKernelGGL((layernorm_v8_kernel<1, 16>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
+      FFSR_LAUNCH((layernorm_v8_kernel<1, 16>), grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1,
                          ldr1, res2, ldr2, r2vec, rpb, M, C);
     return ffsr_launch_status();
   }
 #define FFSR_LN(NP)                                                                                                      \
-  hipLaunchKernelGGL(layernorm_v8_kernel<NP>, grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1, \
+  FFSR_LAUNCH(layernorm_v8_kernel<NP>, grid, block, 0, ST, x, ldx, gamma, beta, eps, out, ldo, oh, ol, ldp, res1, \
                      ldr1, res2, ldr2, r2vec, rpb, M, C)
   if (C <= 256) FFSR_LN(1);
   else if (C <= 512) FFSR_LN(2);
@@ -642,10 +642,10 @@ extern "C" int ffsr_unary_f32(const float* x, int ldx, float* out, int ldo, long
   FFSR_CHECK(x && out && M > 0 && C > 0);
   bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && al16(x) && al16(out);
   if (v4)
-    hipLaunchKernelGGL(unary_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, x, ldx, out, ldo, M, C, act, slope,
+    FFSR_LAUNCH(unary_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, x, ldx, out, ldo, M, C, act, slope,
                        pre, alpha, beta, cscale, cbias, do_clamp, lo, hi);
   else
-    hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, x, ldx, out, ldo, M, C, act, slope, pre, alpha,
+    FFSR_LAUNCH(unary_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, x, ldx, out, ldo, M, C, act, slope, pre, alpha,
                        beta, cscale, cbias, do_clamp, lo, hi);
   return ffsr_launch_status();
 }
@@ -656,10 +656,10 @@ extern "C" int ffsr_scale_add_f32(const float* a, int lda, const float* avec, co
   FFSR_CHECK(a && out && M > 0 && C > 0 && rows_per_batch > 0);
   bool v4 = (C % 4 == 0) && (lda % 4 == 0) && (ldo % 4 == 0) && (!b || ldb % 4 == 0) && al16(a) && al16(out) && (!b || al16(b));
   if (v4)
-    hipLaunchKernelGGL(scale_add_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, a, lda, avec, b, ldb, bvec,
+    FFSR_LAUNCH(scale_add_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, a, lda, avec, b, ldb, bvec,
                        rows_per_batch, out, ldo, M, C, alpha, beta);
   else
-    hipLaunchKernelGGL(scale_add_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, a, lda, avec, b, ldb, bvec,
+    FFSR_LAUNCH(scale_add_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, a, lda, avec, b, ldb, bvec,
                        rows_per_batch, out, ldo, M, C, alpha, beta);
   return ffsr_launch_status();
 }
@@ -670,10 +670,10 @@ extern "C" int ffsr_mul_add_f32(const float* a, int lda, const float* b, int ldb
   bool v4 = (C % 4 == 0) && (lda % 4 == 0) && (ldo % 4 == 0) && (bmode == 1 || ldb % 4 == 0) && (!c || ldc % 4 == 0) &&
             al16(a) && al16(out) && (bmode == 1 || al16(b)) && (!c || al16(c));
   if (v4)
-    hipLaunchKernelGGL(mul_add_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, a, lda, b, ldb, bmode, c, ldc, out,
+    FFSR_LAUNCH(mul_add_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, a, lda, b, ldb, bmode, c, ldc, out,
                        ldo, M, C, alpha, gamma);
   else
-    hipLaunchKernelGGL(mul_add_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, a, lda, b, ldb, bmode, c, ldc, out, ldo,
+    FFSR_LAUNCH(mul_add_kernel<1>, dim3(grid_for(M * C)), dim3(256), 0, ST, a, lda, b, ldb, bmode, c, ldc, out, ldo,
                        M, C, alpha, gamma);
   return ffsr_launch_status();
 }
@@ -681,8 +681,8 @@ extern "C" int ffsr_mul_add_f32(const float* a, int lda, const float* b, int ldb
 extern "C" int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part, int B, int R, int C, int nchunk,
                                 void* stream) {
   FFSR_CHECK(x && out && part && B > 0 && R > 0 && C > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, out, B, C, nchunk, 1.0f / (float)R);
+  FFSR_LAUNCH(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, out, B, C, nchunk, 1.0f / (float)R);
   return ffsr_launch_status();
 }
 
@@ -693,16 +693,16 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
   if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && pix >= 4096 && B <= 65535) {   // sliding-window kernel
     const long long per_img = (long long)H * W;
     const int nchunk = (int)(per_img / 256 < 1 ? 1 : (per_img / 256 > 8192 ? 8192 : per_img / 256));
-    hipLaunchKernelGGL(dw3x3_run_kernel<false>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo,
+    FFSR_LAUNCH(dw3x3_run_kernel<false>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo,
                        nullptr, H, W, C, nchunk, act);
     return ffsr_launch_status();
   }
   bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out) && al16(w);
   if (v4)
-    hipLaunchKernelGGL(dwconv_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W,
+    FFSR_LAUNCH(dwconv_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W,
                        C, KH, KW, pad_h, pad_w, act);
   else
-    hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W, C,
+    FFSR_LAUNCH(dwconv_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, B, H, W, C,
                        KH, KW, pad_h, pad_w, act);
   return ffsr_launch_status();
 }
@@ -710,9 +710,9 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
 extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
                                         float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream) {
   FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
-  hipLaunchKernelGGL(dw3x3_run_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
+  FFSR_LAUNCH(dw3x3_run_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
                      H, W, C, nchunk, 0);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, pooled, B, C, nchunk,
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, pooled, B, C, nchunk,
                      1.0f / (float)(H * W));
   return ffsr_launch_status();
 }
@@ -724,10 +724,10 @@ extern "C" int ffsr_bilinear_f32(const float* in, int ldi, float* out, int ldo, 
   long long pix = (long long)B * Ho * Wo;
   bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out);
   if (v4)
-    hipLaunchKernelGGL(bilinear_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi, Wi, Ho,
+    FFSR_LAUNCH(bilinear_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi, Wi, Ho,
                        Wo, C, sh, sw, mul, accumulate);
   else
-    hipLaunchKernelGGL(bilinear_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi, Wi, Ho, Wo, C,
+    FFSR_LAUNCH(bilinear_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi, Wi, Ho, Wo, C,
                        sh, sw, mul, accumulate);
   return ffsr_launch_status();
 }
@@ -735,7 +735,7 @@ extern "C" int ffsr_bilinear_f32(const float* in, int ldi, float* out, int ldo, 
 extern "C" int ffsr_bicubic_up_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int scale,
                                    void* stream) {
   FFSR_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && scale > 0);
-  hipLaunchKernelGGL(bicubic_up_kernel, dim3(grid_for((long long)B * H * W * scale * scale * C)), dim3(256), 0, ST, in, ldi,
+  FFSR_LAUNCH(bicubic_up_kernel, dim3(grid_for((long long)B * H * W * scale * scale * C)), dim3(256), 0, ST, in, ldi,
                      out, ldo, B, H, W, C, scale);
   return ffsr_launch_status();
 }
@@ -745,28 +745,28 @@ extern "C" int ffsr_avgpool2_f32(const float* in, int ldi, float* out, int ldo, 
   long long pix = (long long)B * (H / 2) * (W / 2);
   bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && al16(in) && al16(out);
   if (v4)
-    hipLaunchKernelGGL(avgpool2_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, C);
+    FFSR_LAUNCH(avgpool2_kernel<4>, dim3(grid_for(pix * (C / 4))), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, C);
   else
-    hipLaunchKernelGGL(avgpool2_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, C);
+    FFSR_LAUNCH(avgpool2_kernel<1>, dim3(grid_for(pix * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, C);
   return ffsr_launch_status();
 }
 
 extern "C" int ffsr_u8_to_f32(const unsigned char* in, float* out, int ldo, long long M, int C, void* stream) {
   FFSR_CHECK(in && out && M > 0 && C > 0 && ldo >= C);
-  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(M * C)), dim3(256), 0, ST, in, out, ldo, M, C);
+  FFSR_LAUNCH(u8_to_f32_kernel, dim3(grid_for(M * C)), dim3(256), 0, ST, in, out, ldo, M, C);
   return ffsr_launch_status();
 }
 
 extern "C" int ffsr_f32_to_u8(const float* in, int ldi, unsigned char* out, long long M, int C, void* stream) {
   FFSR_CHECK(in && out && M > 0 && C > 0 && ldi >= C);
-  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for(M * C)), dim3(256), 0, ST, in, ldi, out, M, C);
+  FFSR_LAUNCH(f32_to_u8_kernel, dim3(grid_for(M * C)), dim3(256), 0, ST, in, ldi, out, M, C);
   return ffsr_launch_status();
 }
 
 extern "C" int ffsr_pad_reflect_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Hp, int Wp, int C,
                                     void* stream) {
   FFSR_CHECK(in && out && B > 0 && H > 1 && W > 1 && Hp >= H && Wp >= W && Hp - H < H && Wp - W < W && C > 0);
-  hipLaunchKernelGGL(pad_reflect_kernel, dim3(grid_for((long long)B * Hp * Wp * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H,
+  FFSR_LAUNCH(pad_reflect_kernel, dim3(grid_for((long long)B * Hp * Wp * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H,
                      W, Hp, Wp, C);
   return ffsr_launch_status();
 }
@@ -774,7 +774,7 @@ extern "C" int ffsr_pad_reflect_f32(const float* in, int ldi, float* out, int ld
 extern "C" int ffsr_crop_f32(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int Ho, int Wo, int C,
                              int do_clamp, void* stream) {
   FFSR_CHECK(in && out && B > 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W && C > 0);
-  hipLaunchKernelGGL(crop_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, Ho,
+  FFSR_LAUNCH(crop_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, H, W, Ho,
                      Wo, C, do_clamp);
   return ffsr_launch_status();
 }
@@ -790,7 +790,7 @@ extern "C" int ffsr_dihedral_f32(const float* in, int ldi, float* out, int ldo, 
       int y = ay_i * is[a] + ay_j * js[b] + cy, x = ax_i * is[a] + ax_j * js[b] + cx;
       FFSR_CHECK(y >= 0 && y < Hi && x >= 0 && x < Wi);
     }
-  hipLaunchKernelGGL(dihedral_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi,
+  FFSR_LAUNCH(dihedral_kernel, dim3(grid_for((long long)B * Ho * Wo * C)), dim3(256), 0, ST, in, ldi, out, ldo, B, Hi,
                      Wi, Ho, Wo, C, ay_i, ay_j, cy, ax_i, ax_j, cx, scale, accumulate);
   return ffsr_launch_status();
 }

@@ -319,10 +319,10 @@ __global__ __launch_bounds__(256) void mamba_norm_gate_v8_kernel(const float* __
 template <int R>
 int run_scan(const ScanArgs& a, hipStream_t st) {
   dim3 grid((a.Dm + 63) / 64, a.nchunk, 4 * a.B);
-  hipLaunchKernelGGL((scan_chunk_kernel<R, false>), grid, dim3(64), 0, st, a);
-  hipLaunchKernelGGL(scan_carry_kernel, dim3((a.Dm * NS + 63) / 64, a.B * 4), dim3(64 * CARRY_SEG), 0, st, a.hstate, a.decay,
+  FFSR_LAUNCH((scan_chunk_kernel<R, false>), grid, dim3(64), 0, st, a);
+  FFSR_LAUNCH(scan_carry_kernel, dim3((a.Dm * NS + 63) / 64, a.B * 4), dim3(64 * CARRY_SEG), 0, st, a.hstate, a.decay,
                      a.nchunk, a.Dm * NS);
-  hipLaunchKernelGGL((scan_chunk_kernel<R, true>), grid, dim3(64), 0, st, a);
+  FFSR_LAUNCH((scan_chunk_kernel<R, true>), grid, dim3(64), 0, st, a);
   return ffsr_launch_status();
 }
 
@@ -359,17 +359,17 @@ extern "C" int ffsr_mamba_norm_gate_planes_f32(const float* y, long long ystride
   hipStream_t st = (hipStream_t)stream;
   if (!v8) {
     FFSR_CHECK(out && !out_hi);
-    hipLaunchKernelGGL(mamba_norm_gate_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz, gamma,
+    FFSR_LAUNCH(mamba_norm_gate_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz, gamma,
                        beta, eps, out, ldo, M, C);
     return ffsr_launch_status();
   }
   unsigned short* oh = (unsigned short*)out_hi;
   unsigned short* ol = (unsigned short*)out_lo;
   if (C <= 256)
-    hipLaunchKernelGGL(mamba_norm_gate_v8_kernel<1>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
+    FFSR_LAUNCH(mamba_norm_gate_v8_kernel<1>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
                        gamma, beta, eps, out, ldo, oh, ol, ldp, M, C);
   else
-    hipLaunchKernelGGL(mamba_norm_gate_v8_kernel<2>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
+    FFSR_LAUNCH(mamba_norm_gate_v8_kernel<2>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
                        gamma, beta, eps, out, ldo, oh, ol, ldp, M, C);
   return ffsr_launch_status();
 }

@@ -44,6 +44,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FfsrError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or `make -C image-super-resolution_amd/csrc` (there is no CPU fallback)")
+        # torch ships its own HIP runtime: it must be the one this process binds (the library launches on torch's streams),
+        # so make sure it is loaded before our .so pulls in a libamdhip64 by SONAME
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, argtypes in parse_header().items():
             fn = getattr(handle, name)      # AttributeError if the .so does not export a declared symbol
