@@ -30,12 +30,15 @@ class _Block:
 
     def __call__(self, x):
         c = self.c
-        t = ops.layernorm(x, *self.n1, eps=1e-6)
+        # deep levels (c >= 256: long K, few pixels) are MFMA-heavy: their LayerNorm outputs go to the GEMM as bf16
+        # hi/lo planes; the shallow levels are HBM-bound either way and keep the fp32 path
+        pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3" and c >= 256
+        t = ops.layernorm(x, *self.n1, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
         t = ops.conv2d(t, self.conv1)
         g, pooled = ops.dw3x3_gate_pool(t, self.dw)              # SimpleGate + global average pool
         sca = ops.linear(pooled, self.sca)                       # [B, c] channel attention
         y = ops.conv2d(g, self.conv3, akscale=sca.contiguous(), res=x, cvec=self.beta)   # x + conv3(g*sca)*beta
-        t = ops.conv2d(ops.layernorm(y, *self.n2, eps=1e-6), self.conv4)
+        t = ops.conv2d(ops.layernorm(y, *self.n2, eps=1e-6, out_planes=True if pl else None, want_f32=not pl), self.conv4)
         g = ops.mul_add(t[..., :c], t[..., c:])                  # SimpleGate
         return ops.conv2d(g, self.conv5, res=y, cvec=self.gamma)
 
