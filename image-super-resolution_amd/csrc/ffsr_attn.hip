@@ -319,7 +319,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (KS <= 2 ? 4 : (KS <= 4 ? 3
   };
   // ---- K / V tile loader: 64 tokens -> K planes [64][RSK] (as load_rows) and TRANSPOSED V planes [d][64 keys]
   // (lane = channel, this wave's RPW keys as packed pairs).  Every global load of the tile is issued before the first
-  // conversion, so the workgroup pays ONE exposed memory latency per tile.
+  // conversion, so the workgroup pays ONE exposed memory latency per tile.  (Measured and rejected: issuing the loads of
+  // tile t+1 before the work on tile t -- 48-64 more live registers cost a wave per SIMD: 0-12 % slower.)
   constexpr int DI = HDP > 64 ? 2 : 1;
   auto load_kv = [&](int tok0) {
     float kreg[RPW][2], vreg[DI][RPW];
