@@ -486,6 +486,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (KS <= 2 ? 4 : (KS <= 4 ? 3
 // --------------------------------------------------------------------------------------------------------------
 // (2) GRL attention: one wave per (window, head).  Tokens of an 8x8 window; lane = query token.
 // --------------------------------------------------------------------------------------------------------------
+// 1-D grid, workgroups dealt round-robin over the 8 XCDs: give every XCD a contiguous range of logical ids (bijective
+// for any grid size).  All heads of a window read the same qkv rows (each only HD of their floats); with the head as the
+// fastest logical index they run at the same time on CUs of ONE L2 instead of re-fetching the rows per XCD.
+__device__ __forceinline__ int xcd_logical_id() {
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+}
+
 __device__ __forceinline__ float inv_norm(const float* v, int n) {
   float s = 0.f;
   for (int i = 0; i < n; ++i) s = fmaf(v[i], v[i], s);
@@ -504,9 +513,10 @@ __global__ __launch_bounds__(64) void grl_window_kernel(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float Vs[N][HD + 2];
   __shared__ int regs[N];
   const int lane = threadIdx.x;
-  const int head = blockIdx.y;
+  const int logical = xcd_logical_id();                 // XCD-aware order, head fastest: the heads of a window share one L2
+  const int head = logical % heads;
   const int nwx = W / WS, nwy = H / WS;
-  const int win = blockIdx.x % (nwx * nwy), b = blockIdx.x / (nwx * nwy);
+  const int win = (logical / heads) % (nwx * nwy), b = (logical / heads) / (nwx * nwy);
   const int wy = win / nwx, wx = win % nwx;
   const int ys = wy * WS + lane / WS, xs = wx * WS + lane % WS;
   int y = ys + shift, x = xs + shift;
@@ -564,6 +574,11 @@ __global__ __launch_bounds__(64) void grl_window_kernel(const float* __restrict_
   for (int d = 0; d < HD; ++d) orow[d] = o[d];
 }
 
+// (Measured and rejected: an LDS-free split-bf16 MFMA form of this kernel -- K / Q / V fetched from global memory straight
+// into MFMA fragment layout, 48 MFMAs per window-head instead of ~8000 FMAs per lane -- runs in the same 170 us as the
+// VALU kernel at 352x512: with 120-byte row slices per head the kernel is bound by its scattered global reads, not by
+// arithmetic.  What helps is the XCD-aware, head-fastest order above (-6 %).)
+
 // anchors: [B, H/2, W/2, lda] with head h at column h*HD.  bias1T: [heads][64 keys][16 anchors] (anchor <- window),
 // bias2T: [heads][16 anchors][64 queries] (window <- anchor).  No stripe shift in GRL-B (grl/__init__.py:139).
 template <int HD>
@@ -579,9 +594,10 @@ __global__ __launch_bounds__(64) void grl_stripe_kernel(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float Gs[NA][HD + 2];   // anchors' gathered values
   __shared__ float P1[NA][N + 1];
   const int lane = threadIdx.x;
-  const int head = blockIdx.y;
+  const int logical = xcd_logical_id();                 // XCD-aware order, head fastest: the heads of a window share one L2
+  const int head = logical % heads;
   const int nwx = W / WS, nwy = H / WS;
-  const int win = blockIdx.x % (nwx * nwy), b = blockIdx.x / (nwx * nwy);
+  const int win = (logical / heads) % (nwx * nwy), b = (logical / heads) / (nwx * nwy);
   const int wy = win / nwx, wx = win % nwx;
   const int y = wy * WS + lane / WS, x = wx * WS + lane % WS;
   const size_t pix = ((size_t)b * H + y) * W + x;
@@ -821,7 +837,7 @@ extern "C" int ffsr_grl_window_attn_f32(const float* qkv, int ldq, int col0, con
                                         float* out, int ldo, int ocol0, int B, int H, int W, int heads, int hd, int shift,
                                         void* stream) {
   FFSR_CHECK(qkv && biasT && logit && out && B > 0 && H % 8 == 0 && W % 8 == 0 && heads > 0 && shift >= 0 && shift < 8);
-  dim3 grid((H / 8) * (W / 8) * B, heads);
+  dim3 grid((unsigned)((H / 8) * (W / 8) * B * heads));
   switch (hd) {
     case 30: FFSR_LAUNCH(grl_window_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
     case 10: FFSR_LAUNCH(grl_window_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, biasT, logit, out, ldo, ocol0, H, W, heads, shift); break;
@@ -834,7 +850,7 @@ extern "C" int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, con
                                         const float* bias1T, const float* bias2T, const float* logit1, const float* logit2,
                                         float* out, int ldo, int ocol0, int B, int H, int W, int heads, int hd, void* stream) {
   FFSR_CHECK(qkv && anchor && bias1T && bias2T && logit1 && logit2 && out && B > 0 && H % 8 == 0 && W % 8 == 0 && heads > 0);
-  dim3 grid((H / 8) * (W / 8) * B, heads);
+  dim3 grid((unsigned)((H / 8) * (W / 8) * B * heads));
   switch (hd) {
     case 30: FFSR_LAUNCH(grl_stripe_kernel<30>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;
     case 10: FFSR_LAUNCH(grl_stripe_kernel<10>, grid, dim3(64), 0, ST, qkv, ldq, col0, anchor, lda, bias1T, bias2T, logit1, logit2, out, ldo, ocol0, H, W, heads); break;

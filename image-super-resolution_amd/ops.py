@@ -31,6 +31,7 @@ BN128_MIN_N = 1 << 30   # the 128-column tile (2 waves/SIMD) measured slower on 
 
 
 def set_gemm_mode(mode: str):
+    """"bf16x3": GEMMs, convs and DRCT's window attention on the split-bf16 MFMA; "f32": the exact kernels everywhere."""
     global GEMM_MODE
     assert mode in ("f32", "bf16x3")
     GEMM_MODE = mode

@@ -154,6 +154,7 @@ int ffsr_window_attn_f32(const float* qkv, int ldq, const float* bias, float* ou
  * logit [heads] = exp(min(logit_scale, ln 100)).  Output written at columns ocol0 + head*hd. */
 int ffsr_grl_window_attn_f32(const float* qkv, int ldq, int col0, const float* biasT, const float* logit, float* out,
                              int ldo, int ocol0, int B, int H, int W, int heads, int hd, int shift, void* stream);
+
 /* GRL anchored stripe attention, both hops fused (mixed_attn_block_efficient.py:215-270); anchor [B,H/2,W/2,lda]. */
 int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, const float* anchor, int lda, const float* bias1T,
                              const float* bias2T, const float* logit1, const float* logit2, float* out, int ldo,

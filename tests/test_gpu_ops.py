@@ -183,6 +183,34 @@ def test_window_attn(ops, C, heads, shift, H, W, variant, tol):
     close(got.cpu(), o.reshape(B * H * W, C), tol, "window attention")
 
 
+@pytest.mark.parametrize("heads,hd,shift,H,W", [(3, 30, 0, 16, 24), (3, 30, 4, 24, 16), (2, 10, 4, 16, 16)])
+def test_grl_window_attn(ops, heads, hd, shift, H, W):
+    """GRL's cosine window attention (mixed_attn_block_efficient.py:77-165): normalised q.k * logit + CPB bias (+ shift
+    mask), one branch of the shared qkv tensor (column offset, [3][heads][hd] layout)."""
+    from ffsr_oracle.common import win_split, win_merge, shift_mask
+    B, ws, Cb = 2, 8, heads * hd
+    col0, ldq = 6, 3 * Cb + 10
+    qkv = rnd(B * H * W, ldq, seed=1)
+    bias = rnd(heads, 64, 64, seed=2)                        # [heads, query, key]
+    logit = rnd(heads, seed=3).abs() + 0.5
+    t = qkv[:, col0:col0 + 3 * Cb].reshape(B, H, W, 3 * Cb)
+    if shift:
+        t = torch.roll(t, (-shift, -shift), (1, 2))
+    w = win_split(t, ws, ws).reshape(-1, 64, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    a = F.normalize(w[0], dim=-1) @ F.normalize(w[1], dim=-1).transpose(-2, -1) * logit[None, :, None, None] + bias[None]
+    if shift:
+        m = shift_mask(H, W, ws, ws, shift, shift)
+        a = (a.reshape(B, -1, heads, 64, 64) + m[None, :, None]).reshape(-1, heads, 64, 64)
+    o = win_merge((a.softmax(-1) @ w[2]).transpose(1, 2).reshape(-1, 64, Cb), ws, ws, H, W)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    out = torch.zeros(B * H * W, Cb + 8, device=DEV)
+    ops.grl_window_attn(qkv.to(DEV), col0, bias.permute(0, 2, 1).contiguous().to(DEV), logit.to(DEV), out, 4, B, H, W, heads,
+                        hd, shift)
+    close(out[:, 4:4 + Cb].cpu(), o.reshape(B * H * W, Cb), 2e-5, "grl window attention")
+    assert (out[:, :4] == 0).all() and (out[:, 4 + Cb:] == 0).all()
+
+
 def test_pixel_mha(ops):
     for T, E_, heads in ((9, 64, 4), (4, 128, 8)):
         S = 301
