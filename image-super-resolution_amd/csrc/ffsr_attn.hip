@@ -289,74 +289,85 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (KS <= 2 ? 4 : (KS <= 4 ? 3
   const float* qbase = p.qkv + head * hd;
   const int q0 = (NW == 4 ? zq * 128 : 0) + wave * 32;   // first query (window token) of this wave
 
-  // ---- row loader (K tile / Q round): 64 tokens -> bf16 hi / lo planes [64][RSK]; lane = channel pair (2l, 2l+1).
+  // ---- row loader (K tile / Q round): 64 tokens -> bf16 hi / lo planes [64][RSK].  A row slice is only head_dim floats
+  // (120 B at head_dim 30): one row per load instruction would use 15 of the 64 lanes, so the lanes are split into LR
+  // rows x LP channel pairs (LP = HDP/2 rounded up to a power of two) and every instruction fetches LR rows.
   // All global loads of a batch are issued before the conversions (clamped column + 0/1 mask, no branches around loads).
-  const int d0 = 2 * lane;
+  constexpr int LP = HDP <= 32 ? 16 : (HDP <= 64 ? 32 : 64), LR = 64 / LP;   // lanes per row, rows per instruction
+  constexpr int KI = RPW / LR;                                               // row-load instructions per wave and tile
+  const int pr = lane % LP, rl = lane / LP;
+  const int d0 = 2 * pr;
   const float m0 = d0 < hd ? 1.f : 0.f, m1 = d0 + 1 < hd ? 1.f : 0.f;
   const int c0 = min(d0, hd - 1), c1 = min(d0 + 1, hd - 1);
   auto load_rows = [&](int tok0, int col0, float scale) {
-#pragma unroll 1
-    for (int batch = 0; batch < RPW / 8; ++batch) {
-      float reg[8][2];
+    float reg[KI][2];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int rr = wave + NW * (batch * 8 + r);
-        const float* src = qbase + (size_t)tok_pix[tok0 + rr] * p.ldq + col0;
-        reg[r][0] = src[c0];
-        reg[r][1] = src[c1];
-      }
-      if (d0 < HDP) {
+    for (int i = 0; i < KI; ++i) {
+      const int rr = RPW * wave + LR * i + rl;
+      const float* src = qbase + (size_t)tok_pix[tok0 + rr] * p.ldq + col0;
+      reg[i][0] = src[c0];
+      reg[i][1] = src[c1];
+    }
+    if (d0 < HDP) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int rr = wave + NW * (batch * 8 + r);
-          unsigned h, l;
-          ffsr_split2(reg[r][0] * m0 * scale, reg[r][1] * m1 * scale, h, l);
-          *reinterpret_cast<unsigned*>(Khi + rr * RSK + lane * 4) = h;
-          *reinterpret_cast<unsigned*>(Klo + rr * RSK + lane * 4) = l;
-        }
+      for (int i = 0; i < KI; ++i) {
+        const int rr = RPW * wave + LR * i + rl;
+        unsigned h, l;
+        ffsr_split2(reg[i][0] * m0 * scale, reg[i][1] * m1 * scale, h, l);
+        *reinterpret_cast<unsigned*>(Khi + rr * RSK + pr * 4) = h;
+        *reinterpret_cast<unsigned*>(Klo + rr * RSK + pr * 4) = l;
       }
     }
   };
   // ---- K / V tile loader: 64 tokens -> K planes [64][RSK] (as load_rows) and TRANSPOSED V planes [d][64 keys]
-  // (lane = channel, this wave's RPW keys as packed pairs).  Every global load of the tile is issued before the first
-  // conversion, so the workgroup pays ONE exposed memory latency per tile.  (Measured and rejected: issuing the loads of
-  // tile t+1 before the work on tile t -- 48-64 more live registers cost a wave per SIMD: 0-12 % slower.)
+  // (lanes = LVR key pairs x LV channels, this wave's RPW keys as packed pairs).  Every global load of the tile is issued
+  // before the first conversion, so the workgroup pays ONE exposed memory latency per tile.  (Measured and rejected:
+  // issuing the loads of tile t+1 before the work on tile t -- 48-64 more live registers cost a wave per SIMD: 0-12 %
+  // slower.)
   constexpr int DI = HDP > 64 ? 2 : 1;
+  constexpr int LV = HDP <= 32 ? 32 : 64, LVR = 64 / LV;      // channel lanes, key pairs per instruction
+  constexpr int VI = RPW / (2 * LVR);                          // key-pair rounds per wave and tile
+  const int vd = lane % LV, vg = lane / LV;
   auto load_kv = [&](int tok0) {
-    float kreg[RPW][2], vreg[DI][RPW];
+    float kreg[KI][2], vreg[DI][VI][2];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const float* src = qbase + (size_t)tok_pix[tok0 + wave + NW * r] * p.ldq + p.C;
-      kreg[r][0] = src[c0];
-      kreg[r][1] = src[c1];
+    for (int i = 0; i < KI; ++i) {
+      const float* src = qbase + (size_t)tok_pix[tok0 + RPW * wave + LR * i + rl] * p.ldq + p.C;
+      kreg[i][0] = src[c0];
+      kreg[i][1] = src[c1];
     }
 #pragma unroll
     for (int di = 0; di < DI; ++di) {
-      const int cc = min(lane + 64 * di, hd - 1);
+      const int cc = min(vd + 64 * di, hd - 1);
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) vreg[di][r] = (qbase + (size_t)tok_pix[tok0 + RPW * wave + r] * p.ldq + 2 * p.C)[cc];
+      for (int i = 0; i < VI; ++i) {
+        const int key = RPW * wave + 2 * (LVR * i + vg);
+        vreg[di][i][0] = (qbase + (size_t)tok_pix[tok0 + key] * p.ldq + 2 * p.C)[cc];
+        vreg[di][i][1] = (qbase + (size_t)tok_pix[tok0 + key + 1] * p.ldq + 2 * p.C)[cc];
+      }
     }
     if (d0 < HDP) {
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const int rr = wave + NW * r;
+      for (int i = 0; i < KI; ++i) {
+        const int rr = RPW * wave + LR * i + rl;
         unsigned h, l;
-        ffsr_split2(kreg[r][0] * m0, kreg[r][1] * m1, h, l);
-        *reinterpret_cast<unsigned*>(Khi + rr * RSK + lane * 4) = h;
-        *reinterpret_cast<unsigned*>(Klo + rr * RSK + lane * 4) = l;
+        ffsr_split2(kreg[i][0] * m0, kreg[i][1] * m1, h, l);
+        *reinterpret_cast<unsigned*>(Khi + rr * RSK + pr * 4) = h;
+        *reinterpret_cast<unsigned*>(Klo + rr * RSK + pr * 4) = l;
       }
     }
 #pragma unroll
     for (int di = 0; di < DI; ++di) {
-      const int d = lane + 64 * di;
+      const int d = vd + 64 * di;
       const float mk = d < hd ? 1.f : 0.f;
       if (d < DT * 32) {
 #pragma unroll
-        for (int pr = 0; pr < RPW / 2; ++pr) {
+        for (int i = 0; i < VI; ++i) {
+          const int key = RPW * wave + 2 * (LVR * i + vg);
           unsigned h, l;
-          ffsr_split2(vreg[di][2 * pr] * mk, vreg[di][2 * pr + 1] * mk, h, l);
-          *reinterpret_cast<unsigned*>(Vhi + d * RSV + (RPW * wave + 2 * pr) * 2) = h;
-          *reinterpret_cast<unsigned*>(Vlo + d * RSV + (RPW * wave + 2 * pr) * 2) = l;
+          ffsr_split2(vreg[di][i][0] * mk, vreg[di][i][1] * mk, h, l);
+          *reinterpret_cast<unsigned*>(Vhi + d * RSV + key * 2) = h;
+          *reinterpret_cast<unsigned*>(Vlo + d * RSV + key * 2) = l;
         }
       }
     }
@@ -577,7 +588,8 @@ __global__ __launch_bounds__(64) void grl_window_kernel(const float* __restrict_
 // (Measured and rejected: an LDS-free split-bf16 MFMA form of this kernel -- K / Q / V fetched from global memory straight
 // into MFMA fragment layout, 48 MFMAs per window-head instead of ~8000 FMAs per lane -- runs in the same 170 us as the
 // VALU kernel at 352x512: with 120-byte row slices per head the kernel is bound by its scattered global reads, not by
-// arithmetic.  What helps is the XCD-aware, head-fastest order above (-6 %).)
+// arithmetic.  What helps is the XCD-aware, head-fastest order above (-6 %).  Also rejected: staging the q / k / v rows
+// through LDS with row-coalesced float2 loads and stores instead of one row per lane -- 181 us against 157 us.)
 
 // anchors: [B, H/2, W/2, lda] with head h at column h*HD.  bias1T: [heads][64 keys][16 anchors] (anchor <- window),
 // bias2T: [heads][16 anchors][64 queries] (window <- anchor).  No stripe shift in GRL-B (grl/__init__.py:139).
