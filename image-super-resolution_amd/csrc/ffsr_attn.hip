@@ -485,12 +485,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (KS <= 2 ? 4 : (KS <= 4 ? 3
   // ---- normalise and store O^T: lane = query, registers = head-dim rows
   const float inv = 1.0f / (lrow + __shfl_xor(lrow, 32, 64));
   float* orow = p.out + (size_t)tok_pix[q0 + r32] * p.ldo + head * hd;
+  // registers 4g .. 4g+3 of a tile are 4 consecutive channels starting at an even d: 8-byte stores whenever this head's
+  // slice starts on an even column (one 4-byte store per lane and channel is store-issue bound: hd 30: 271 -> 237 us)
+  const bool pair_ok = (((head * hd) & 1) == 0) && ((p.ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 7) == 0);
 #pragma unroll
   for (int i = 0; i < DT; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 16; e += 2) {
       const int d = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-      if (d < hd) orow[d] = o[i][e] * inv;
+      if (pair_ok && d + 1 < hd) {
+        *reinterpret_cast<float2*>(orow + d) = float2{o[i][e] * inv, o[i][e + 1] * inv};
+      } else {
+        if (d < hd) orow[d] = o[i][e] * inv;
+        if (d + 1 < hd) orow[d + 1] = o[i][e + 1] * inv;
+      }
     }
 }
 
@@ -589,7 +597,8 @@ __global__ __launch_bounds__(64) void grl_window_kernel(const float* __restrict_
 // into MFMA fragment layout, 48 MFMAs per window-head instead of ~8000 FMAs per lane -- runs in the same 170 us as the
 // VALU kernel at 352x512: with 120-byte row slices per head the kernel is bound by its scattered global reads, not by
 // arithmetic.  What helps is the XCD-aware, head-fastest order above (-6 %).  Also rejected: staging the q / k / v rows
-// through LDS with row-coalesced float2 loads and stores instead of one row per lane -- 181 us against 157 us.)
+// through LDS with row-coalesced float2 loads and stores instead of one row per lane -- 181 us against 157 us; 8-byte
+// instead of 4-byte accesses to the lane's own rows -- no change.)
 
 // anchors: [B, H/2, W/2, lda] with head h at column h*HD.  bias1T: [heads][64 keys][16 anchors] (anchor <- window),
 // bias2T: [heads][16 anchors][64 queries] (window <- anchor).  No stripe shift in GRL-B (grl/__init__.py:139).
