@@ -14,7 +14,9 @@
 // the LDS-DMA stream 2-3 K steps ahead across tile boundaries, 4 consumer waves doing fragments + MFMA + epilogue:
 // correct, 0-10 % SLOWER on every shape (K = 180 token GEMMs and 3x3 convs alike).  With cold caches the K <= 360 token
 // GEMMs already run at 57-84 % of what the chip's plain streaming kernels reach on the same bytes (~4 TB/s): what is
-// left for them is fewer bytes (fusion), not a different pipeline.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
+// left for them is fewer bytes (fusion), not a different pipeline.  (c) One workgroup walking all column tiles of its
+// 128-row panel (the A panel then stays in that CU's L1 / L2): 6-15 % slower -- each tile switch drains the epilogue's
+// stores through the shared vmcnt, and the grid loses parallelism.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
 // ~16 B/clk/CU), not the matrix pipe, is what bounds the 128-row tile on long-K shapes.
 // LDS image of one stage: A_hi | A_lo | B_hi | B_lo, rows of 64 B (32 bf16), no padding: one LDS-DMA instruction
 // writes 16 rows x 64 B lane-linear.  Bank conflicts are removed on the SOURCE side: the 16-byte chunk c of row r is
