@@ -137,3 +137,36 @@ def test_layernorm_scaled_second_residual(ops):
     assert torch.equal(pl.buf, ops.split_planes(out).buf)
     plain = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), res1=r1.to(DEV), res2=r2.to(DEV), res2_vec=vec.to(DEV), rows_per_batch=R)
     assert torch.equal(plain, out)
+
+
+def test_planes_entry_points_reject_bad_arguments(ops, pkg):
+    """Error behaviour of the C ABI: invalid shapes / alignments / unsupported epilogues are rejected with FFSR_EINVAL
+    before any launch (the host raises FfsrError); nothing is written."""
+    import importlib
+    hip = importlib.import_module("image-super-resolution_amd.hip")
+    x = rnd(64, 180, seed=1).to(DEV)
+    cv = ops.pack_conv(rnd(180, 180, seed=2), None, DEV)
+    xp = ops.split_planes(x)
+    out = torch.full((1, 1, 64, 180), 5.0, device=DEV)
+    with pytest.raises(AssertionError):
+        ops.conv2d(xp, cv, act=ops.ACT_SIGMOID)                          # host-side guard: sigmoid stays on the fp32-input kernel
+    z = ops.zero_page(DEV)
+
+    def call(Cp=192, bn=192, bm=128, stages=2, act=0, ldp=0, hi=None, a_hi=None):
+        hip.call("ffsr_conv2d_planes", (xp.hi if a_hi is None else a_hi).data_ptr(), xp.lo.data_ptr(), Cp, cv.phi.data_ptr(), cv.plo.data_ptr(),
+                 cv.phi.shape[0], z.data_ptr(), None, out.data_ptr(), None, None, None, hi, hi, ldp, 1, 1, 64, 180, 180, 0, 1, 1, 1,
+                 0, 0, act, 0.0, 1.0, 1.0, bm, bn, stages, torch.cuda.current_stream().cuda_stream)
+
+    call()                                                               # the valid call succeeds
+    torch.cuda.synchronize()
+    ok = out.clone()
+    out.fill_(5.0)
+    for bad in (dict(Cp=180), dict(bn=96), dict(bm=64), dict(stages=7), dict(act=4), dict(act=5),
+                dict(hi=xp.hi.data_ptr(), ldp=180), dict(a_hi=xp.hi.reshape(-1)[1:])):
+        with pytest.raises(hip.FfsrError, match="invalid argument"):
+            call(**bad)
+    torch.cuda.synchronize()
+    assert (out == 5.0).all() and not (ok == 5.0).all()
+    with pytest.raises(hip.FfsrError, match="invalid argument"):           # LayerNorm planes need the vectorised path
+        hip.call("ffsr_layernorm_planes_f32", x.data_ptr(), 180, x.data_ptr(), x.data_ptr(), 1e-5, None, 0, xp.hi.data_ptr(),
+                 xp.lo.data_ptr(), 160, None, 0, None, 0, None, 0, 64, 180, torch.cuda.current_stream().cuda_stream)
