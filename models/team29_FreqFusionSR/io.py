@@ -81,7 +81,9 @@ def main(model_dir, input_path, output_path, device=None):
     print(f"  Processing {len(mine)} of {len(input_imgs)} images on rank {rank}/{world} ...")
     # host pipeline: the next image is decoded and the previous results are encoded on worker threads while the GPU
     # works on the current one; everything is joined before returning (test.py times the whole call, test.py:63-70)
+    import time
     from concurrent.futures import ThreadPoolExecutor
+    t_loop, out_px = time.perf_counter(), 0
     with ThreadPoolExecutor(max_workers=int(os.environ.get("FFSR_IO_THREADS", "4"))) as pool:
         saves = []
         nxt = pool.submit(_imread_uint, mine[0]) if mine else None
@@ -90,10 +92,13 @@ def main(model_dir, input_path, output_path, device=None):
             nxt = pool.submit(_imread_uint, mine[i + 1]) if i + 1 < len(mine) else None
             name, ext = os.path.splitext(os.path.basename(img_path))
             sr = eng.process_u8(img)
+            out_px += sr.shape[0] * sr.shape[1]
             saves.append(pool.submit(_imsave, sr, os.path.join(output_path, name + ext)))
         for f in saves:
             f.result()
     torch.cuda.synchronize(device)
     if world > 1:
         torch.distributed.barrier()
-    print(f"  Done -- {len(mine)} images saved to {output_path}")
+    t_loop = time.perf_counter() - t_loop
+    print(f"  Done -- {len(mine)} images saved to {output_path} "
+          f"({t_loop:.2f} s for the image loop incl. decode / encode = {out_px / 1e6 / max(t_loop, 1e-9):.2f} output-MP/s on this rank)")
