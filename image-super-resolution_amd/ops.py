@@ -170,34 +170,36 @@ class Conv:
 
 def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
               in_perm=None) -> Conv:
-    """w: [N, Cin, KH, KW] (nn.Conv2d) or [N, K] (nn.Linear).  cin_pad: padded channel count of the input map."""
-    w = w.detach().float()
+    """w: [N, Cin, KH, KW] (nn.Conv2d) or [N, K] (nn.Linear).  cin_pad: padded channel count of the input map.
+    Load-time weight preparation (layout change, zero padding, bf16 hi/lo split): done with torch ops on `device`."""
+    w = w.detach().float().to(device)
     if w.dim() == 2:
         w = w[:, :, None, None]
     N, Cin, KH, KW = w.shape
     Cp = cin_pad if cin_pad is not None else pad4(Cin)
     assert Cp >= Cin and Cp % 4 == 0
-    wp = torch.zeros(N, KH, KW, Cp, dtype=torch.float32)
-    wp[..., :Cin] = w.permute(0, 2, 3, 1)
+    wt = w.permute(0, 2, 3, 1)                                             # [N, KH, KW, Cin]
+    wp = torch.zeros(N, KH, KW, Cp, dtype=torch.float32, device=device)
+    wp[..., :Cin] = wt
     if pad is None:
         pad = KH // 2
     w2 = wp.reshape(N, KH * KW * Cp).contiguous()
     # pre-split planes for the bf16x3 kernel: hi = bf16(w), lo = bf16(w - hi); rows padded to x128, K to x32
     Np, Kp = (N + 127) // 128 * 128, (KH * KW * Cp + 31) // 32 * 32
-    hi = torch.zeros(Np, Kp, dtype=torch.bfloat16)
-    lo = torch.zeros(Np, Kp, dtype=torch.bfloat16)
+    hi = torch.zeros(Np, Kp, dtype=torch.bfloat16, device=device)
+    lo = torch.zeros(Np, Kp, dtype=torch.bfloat16, device=device)
     h = w2.to(torch.bfloat16)
     hi[:N, :w2.shape[1]] = h
     lo[:N, :w2.shape[1]] = (w2 - h.float()).to(torch.bfloat16)
     # planes path: every tap padded to a multiple of 32 channels, rows padded to x768 (any column tile of 64/128/192/256)
     C32, Np3 = pad32(Cin), (N + 767) // 768 * 768
-    w3 = torch.zeros(Np3, KH, KW, C32, dtype=torch.float32)
-    w3[:N, :, :, :Cin] = w.permute(0, 2, 3, 1)
+    w3 = torch.zeros(Np3, KH, KW, C32, dtype=torch.float32, device=device)
+    w3[:N, :, :, :Cin] = wt
     w3 = w3.reshape(Np3, KH * KW * C32)
     ph = w3.to(torch.bfloat16)
     pl = (w3 - ph.float()).to(torch.bfloat16)
-    return Conv(w2.to(device), None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride,
-                pad, Cin, hi.to(device), lo.to(device), ph.to(device), pl.to(device), C32)
+    return Conv(w2, None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride,
+                pad, Cin, hi, lo, ph, pl, C32)
 
 
 _ZEROS = {}

@@ -37,8 +37,8 @@ def _layout(weights: Dict[str, dict]):
 
 
 def broadcast_weights(weights: Dict[str, dict], device, src: int = 0) -> Dict[str, dict]:
-    """Every rank passes a dict with identical keys/shapes (e.g. weights.random_weights()); the values of rank
-    `src` win.  One flat buffer -> one broadcast (743 MB fp32 for the full model: a few ms over xGMI)."""
+    """Every rank passes a dict with identical keys/shapes (ranks other than `src` only need the shapes:
+    weights.random_weights(shapes_only=True)); the values of rank `src` win.  One flat buffer -> one broadcast (743 MB fp32 for the full model: a few ms over xGMI)."""
     rank, world = rank_world()
     if world == 1 or not dist.is_initialized():
         return weights

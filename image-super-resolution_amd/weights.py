@@ -21,12 +21,18 @@ EXPERT_FILES = {"drct": "DRCT-L_X4.pth", "grl": "GRL-B_SR_x4.pth", "nafnet": "NA
                 "mamba": "MambaIR_x4.pth", "fusion": "fusion_best.pth"}
 
 
+_SHAPES_ONLY = False        # set by random_weights(shapes_only=True): the large random tensors become meta tensors
+
+
 class _Init:
     def __init__(self, seed: int):
         self.g = torch.Generator().manual_seed(seed)
         self.sd: SD = {}
 
     def normal(self, key, shape, std=0.02, mean=0.0):
+        if _SHAPES_ONLY:
+            self.sd[key] = torch.empty(shape, device="meta")
+            return
         self.sd[key] = torch.randn(shape, generator=self.g) * std + mean
 
     def conv(self, key, cout, cin, k=1, bias=True, groups=1, kh=None, kw=None):
@@ -319,14 +325,22 @@ def fusion_state_dict(seed=5) -> SD:
     return I.sd
 
 
-def random_weights(seed=0, small=False) -> Dict[str, SD]:
-    """All five state_dicts.  small=True: reduced-depth experts of the real width for smoke tests."""
-    if small:
-        return {"drct": drct_state_dict(seed + 1, groups=1), "grl": grl_state_dict(seed + 2, depths=(2,)),
-                "nafnet": nafnet_state_dict(seed + 3, width=64, enc=(1, 1, 1, 1), mid=1, dec=(1, 1, 1, 1)),
-                "mamba": mambair_state_dict(seed + 4, depths=(1,)), "fusion": fusion_state_dict(seed + 5)}
-    return {"drct": drct_state_dict(seed + 1), "grl": grl_state_dict(seed + 2), "nafnet": nafnet_state_dict(seed + 3),
-            "mamba": mambair_state_dict(seed + 4), "fusion": fusion_state_dict(seed + 5)}
+def random_weights(seed=0, small=False, shapes_only=False) -> Dict[str, SD]:
+    """All five state_dicts.  small=True: reduced-depth experts of the real width for smoke tests.
+    shapes_only=True: same keys and shapes, but the randomly initialised tensors are meta tensors (no storage) --
+    the key/shape template load_model_dir and broadcast_weights need, without 184 M random numbers."""
+    global _SHAPES_ONLY
+    prev, _SHAPES_ONLY = _SHAPES_ONLY, bool(shapes_only)
+    try:
+        if small:
+            return {"drct": drct_state_dict(seed + 1, groups=1), "grl": grl_state_dict(seed + 2, depths=(2,)),
+                    "nafnet": nafnet_state_dict(seed + 3, width=64, enc=(1, 1, 1, 1), mid=1, dec=(1, 1, 1, 1)),
+                    "mamba": mambair_state_dict(seed + 4, depths=(1,)), "fusion": fusion_state_dict(seed + 5)}
+        return {"drct": drct_state_dict(seed + 1), "grl": grl_state_dict(seed + 2),
+                "nafnet": nafnet_state_dict(seed + 3), "mamba": mambair_state_dict(seed + 4),
+                "fusion": fusion_state_dict(seed + 5)}
+    finally:
+        _SHAPES_ONLY = prev
 
 
 # ---------------------------------------------------------------------------------------------- checkpoints
@@ -375,15 +389,26 @@ def merge_into(template: SD, loaded: SD) -> SD:
     return out
 
 
-def load_model_dir(model_dir: str, templates: Dict[str, SD] = None) -> Dict[str, SD]:
-    """model_dir holds the five files of io.py:130-135; keys absent / mis-shaped keep their template value."""
-    templates = templates or random_weights()
-    out = {}
+def load_model_dir(model_dir: str, templates: Dict[str, SD] = None, defaults=None) -> Dict[str, SD]:
+    """model_dir holds the five files of io.py:130-135; keys absent / mis-shaped keep their template value.
+    `templates` may be a shapes-only template (random_weights(shapes_only=True)): a key the files do not supply
+    is then filled from `defaults()` (default: random_weights()), which stands in for the module's own initialisation
+    and is only evaluated in that case."""
+    templates = templates or random_weights(shapes_only=True)
+    out, filled = {}, None
     for kind, fname in EXPERT_FILES.items():
         path = os.path.join(model_dir, fname)
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         out[kind] = merge_into(templates[kind], load_checkpoint(path, kind))
+        for k, v in out[kind].items():
+            if v.is_meta:
+                if filled is None:
+                    filled = (defaults or random_weights)()
+                if tuple(filled[kind][k].shape) != tuple(v.shape):
+                    raise ValueError(f"default initialisation of {kind}.{k} has shape {tuple(filled[kind][k].shape)}, "
+                                     f"template wants {tuple(v.shape)}")
+                out[kind][k] = filled[kind][k]
     return out
 
 

@@ -61,8 +61,8 @@ def _load_engine(model_dir, device):
                                  f"architecture ({v}) this engine implements")
     weights, shard, engine = _pkg("weights"), _pkg("shard"), _pkg("engine")
     rank, world = shard.init_process_group()
-    templates = weights.random_weights()
-    w = weights.load_model_dir(model_dir, templates) if rank == 0 else templates
+    templates = weights.random_weights(shapes_only=True)      # keys + shapes; values come from the files (rank 0)
+    w = weights.load_model_dir(model_dir, templates, weights.random_weights) if rank == 0 else templates
     w = shard.broadcast_weights(w, device)
     return engine.Engine(w, device, scale), rank, world
 

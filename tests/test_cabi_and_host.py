@@ -74,6 +74,38 @@ def test_checkpoint_conventions(tmp_path):
         W.load_model_dir(str(tmp_path), templ)
 
 
+def test_shapes_only_template_and_lazy_defaults(tmp_path):
+    """io.main's loader path: the template carries keys + shapes only (meta tensors); values come from the files and the
+    default initialisation is evaluated only for keys the files do not supply (expert_loader.py:97-111 keeps the
+    module's own init for those)."""
+    W = mod("weights")
+    small = W.random_weights(seed=3, small=True)
+    shapes = W.random_weights(seed=9, small=True, shapes_only=True)
+    for kind in small:
+        assert list(shapes[kind]) == list(small[kind])
+        assert all(tuple(shapes[kind][k].shape) == tuple(v.shape) for k, v in small[kind].items())
+    assert any(v.is_meta for v in shapes["drct"].values())
+    W.save_model_dir(str(tmp_path), small)
+    calls = []
+
+    def defaults():
+        calls.append(1)
+        return W.random_weights(seed=4, small=True)
+
+    got = W.load_model_dir(str(tmp_path), shapes, defaults)
+    assert not calls                                                   # complete files: nothing random is generated
+    for kind in small:
+        for k, v in small[kind].items():
+            assert not got[kind][k].is_meta and torch.equal(got[kind][k], v), (kind, k)
+    d = torch.load(tmp_path / "DRCT-L_X4.pth")
+    del d["params_ema"]["conv_first.weight"]
+    torch.save(d, tmp_path / "DRCT-L_X4.pth")
+    got = W.load_model_dir(str(tmp_path), shapes, defaults)
+    assert len(calls) == 1
+    assert torch.equal(got["drct"]["conv_first.weight"], W.random_weights(seed=4, small=True)["drct"]["conv_first.weight"])
+    assert torch.equal(got["drct"]["conv_first.bias"], small["drct"]["conv_first.bias"])
+
+
 def test_strided_shard_matches_reference_scheme():
     S = mod("shard")
     items = list(range(10))

@@ -36,7 +36,7 @@ def test_main_on_png_folder(tmp_path):
     # so give it templates of the small architecture through the public hook
     io = importlib.import_module("models.team29_FreqFusionSR.io")
     orig = W.random_weights
-    W.random_weights = lambda seed=0, small=False: orig(seed=seed, small=True)
+    W.random_weights = lambda seed=0, small=False, **kw: orig(seed=seed, small=True, **kw)
     try:
         team.main(model_dir=str(model_dir), input_path=str(inp), output_path=str(out), device=torch.device("cuda"))
     finally:
