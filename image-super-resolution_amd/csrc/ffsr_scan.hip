@@ -13,6 +13,17 @@
 // Parallelisation: lane = channel d (16 states in registers); the sequence is cut into chunks:
 //   pass A: per chunk, local end state with h_in = 0 and the chunk's total decay exp(A * sum delta)
 //   pass B: serial carry over chunks (tiny)            pass C: per chunk, recurrence from the true h_in, emits y.
+//
+// What bounds it (rocprofv3 --pmc at L = 180224, Dm = 360, tools/scan_pmc.sh): the chunk kernels are vector-ALU bound.
+// One step of one wave is ~104 VALU instructions (87 at 4 issue cycles + 17 v_exp/v_log at 8 = SQ_ACTIVE_INST_VALU of
+// ~485 cycles) and, with 4 waves per SIMD, advances every ~410 cycles (SQ_WAVE_CYCLES); LDS (11 broadcast ds_read_b128 per
+// step, no conflicts) and HBM are far from their limits.  Measured and rejected:
+//   * state pairs on v_pk_mul_f32 / v_pk_fma_f32 (104 -> 75 instructions per step): identical time -- a packed f32
+//     instruction occupies the ALU for two passes, so only the lane-operation count matters;
+//   * capping the scan's occupancy (dynamic-LDS pad, 2 instead of 4 waves per SIMD) so that GEMM workgroups of the other
+//     experts' streams could co-reside: MambaIR alone 136 -> 176 ms and the whole step slower by the same 40 ms.
+// What is left is the lane-operation count itself: 16 states x (mul, exp2, mul, fma, fma) per (step, channel, direction),
+// twice (pass A and pass C).
 #include "ffsr_common.h"
 
 namespace {

@@ -2,6 +2,8 @@
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("FFSR_AB_LIB"):          # A/B against another build of the library (tools/ab/*.so)
+    importlib.import_module("image-super-resolution_amd.hip").LIB_PATH = os.path.abspath(os.environ["FFSR_AB_LIB"])
 ops = importlib.import_module("image-super-resolution_amd.ops")
 dev = "cuda"
 B, H, W, Dm, R = 1, 352, 512, 360, 12
