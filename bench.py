@@ -102,7 +102,8 @@ def main():
     torch.cuda.set_device(device)
     S.init_process_group(args.backend)
 
-    weights = W.random_weights(seed=0, small=args.small)
+    # only the broadcast source needs values; the other ranks hand in the key / shape template (meta tensors)
+    weights = W.random_weights(seed=0, small=args.small, shapes_only=(rank != 0))
     weights = S.broadcast_weights(weights, device)          # RCCL over xGMI, rank 0's values win (no-op at N=1)
     eng = E.Engine(weights, device)
     h, w = args.height, args.width

@@ -19,6 +19,13 @@ WORKER = textwrap.dedent("""
     for m in ref:
         for k in ref[m]:
             assert torch.equal(got[m][k], ref[m][k].float()), (m, k)
+    # ranks other than the source only need keys + shapes (meta tensors): what bench.py / io.main hand in there
+    small = W.random_weights(seed=5, small=True, shapes_only=(rank != 0))
+    got = S.broadcast_weights(small, "cpu")
+    ref = W.random_weights(seed=5, small=True)
+    for m in ref:
+        for k in ref[m]:
+            assert not got[m][k].is_meta and torch.equal(got[m][k], ref[m][k].float()), (m, k)
     mine = S.shard(list(range(7)), rank, world)
     stats = S.gather_stats([len(mine), float(rank)], "cpu")
     assert [s[0] for s in stats] == [4.0, 3.0] and [s[1] for s in stats] == [0.0, 1.0]
