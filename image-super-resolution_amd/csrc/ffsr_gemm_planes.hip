@@ -423,6 +423,191 @@ int launch_planes(PlaneArgs& a, hipStream_t st) {
   return launch_planes2<BM, BN, STAGES, false>(a, st);
 }
 
+// ---- 3x3 (stride 1, pad 1) convolutions: the three horizontal taps share their A rows.
+// The tile kernel above fetches a fresh 128-row A tile per tap: the LDS fill (LDS-DMA instructions through the texture path,
+// ~16 B/clk/CU), not the matrix pipe, bounds the thin-N 3x3 convs (N = 45 / 60 / 128: 24..32 KB staged per K step against
+// 0.5..1 us of MFMA).  Output rows are consecutive pixels, so the A rows of tap (ky, kx) are the rows of tap (ky, 0) moved
+// down by kx: one 130-row strip (144 staged) per (ky, 32-channel chunk) serves kx = 0, 1, 2 through fragment reads at row
+// offsets 0 / 1 / 2 -- 9 pieces per plane instead of 24.  What a shifted read picks up across an image border (the
+// neighbouring pixel of the previous / next image row) is zeroed in the fragment registers from the per-row tap mask.
+template <int BN, bool GELU>
+__global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
+  constexpr int BM = 128, TM = 2, TN = BN / 64, NW = 4;
+  constexpr int SROWS = 144;                                  // 130 used, staged in 16-row pieces
+  constexpr int APL = SROWS * 64, ASTRIP = 2 * APL;           // bytes: one plane, one strip (hi | lo)
+  constexpr int PLANE_B = BN * 64, BST = 2 * PLANE_B;
+  constexpr int NB = BN / 16 / NW;                            // B pieces per wave and plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * ASTRIP | 2 * BST
+  unsigned char* const Abase = smem;
+  unsigned char* const Bbase = smem + 2 * ASTRIP;
+
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+  const int tile = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (orig >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 2;
+  const int cpt = p.Cp >> 5;
+  const long long npix = (long long)p.B * p.H * p.W;
+  const ptrdiff_t lo_delta = reinterpret_cast<const unsigned char*>(p.a_lo) - reinterpret_cast<const unsigned char*>(p.a_hi);
+
+  // strip piece pc (16 rows) of super-step (ky, cc) -> strip buffer `buf`: strip row s holds input pixel m0 - 1 + s + (ky - 1) W
+  auto issue_a = [&](int buf, int pc, int ky, int cc) {
+    const int srow = 16 * pc + lrow;
+    const long long q = (long long)m0 - 1 + srow + (long long)(ky - 1) * p.W;
+    const int chunk = (lane & 3) ^ ((srow >> 2) & 3);
+    const bool ok = q >= 0 && q < npix;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.a_hi) + ((size_t)(ok ? q : 0) * p.Cp + cc * 32 + chunk * 8) * 2;
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(p.zeros);
+    unsigned char* dst = Abase + buf * ASTRIP + pc * 1024;
+    __builtin_amdgcn_global_load_lds(ok ? src : zp, (lds_ptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(ok ? src + lo_delta : zp, (lds_ptr_t)(dst + APL), 16, 0, 0);
+  };
+  unsigned b_off[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int row = 16 * (wave + NW * j) + lrow;
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    b_off[j] = (unsigned)((n0 + row) * (p.nk * 32) + chunk * 8) * 2u;
+  }
+  auto issue_b = [&](int buf, int ky, int kx, int cc) {
+    const unsigned koff = (unsigned)(((ky * 3 + kx) * cpt + cc) * 64);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      unsigned char* dst = Bbase + buf * BST + (wave + NW * j) * 1024;
+      const size_t o = (size_t)b_off[j] + koff;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(p.w_hi) + o, (lds_ptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(p.w_lo) + o, (lds_ptr_t)(dst + PLANE_B), 16, 0, 0);
+    }
+  };
+
+  const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (BN / 2);
+  const int r = lane & 31, h = lane >> 5;
+  // per fragment row: bit t of the mask = tap t reads inside the image
+  unsigned fmask[TM];
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wrow + i * 32 + r;
+    unsigned mk = 0;
+    if (m < p.M) {
+      const int rem = m % HW;
+      const int oy = rem / p.W, ox = rem - oy * p.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = oy + t / 3 - 1, xx = ox + t % 3 - 1;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+      }
+    }
+    fmask[i] = mk;
+  }
+  const bool any_masked = __any((fmask[0] & fmask[1]) != 0x1ffu);   // wave-uniform: interior tiles skip the masking
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int swz = (r >> 2) & 3;
+  const int bfo0 = r * 64 + (((0 + h) ^ swz) << 4), bfo1 = r * 64 + (((2 + h) ^ swz) << 4);
+
+  // prologue: strip of super-step 0 (pieces dealt round-robin to the waves) and the weights of step 0
+  for (int pc = wave; pc < SROWS / 16; pc += NW) issue_a(0, pc, 0, 0);
+  issue_b(0, 0, 0, 0);
+
+  const int nss = 3 * cpt;          // super-steps (ky, cc); 3 K steps (kx) each
+  int ky = 0, cc = 0;
+  for (int ss = 0; ss < nss; ++ss) {
+    int nky = ky, ncc = cc + 1;
+    if (ncc == cpt) { ncc = 0; ++nky; }
+    const bool more_ss = ss + 1 < nss;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // this step's strip / weights have landed; the buffers refilled below are no longer read
+      const int t = 3 * ss + kx;
+      // next step's weights; the next super-step's strip is fetched in thirds (pieces 0-3, 4-7, 8) while this one is consumed
+      if (kx < 2) issue_b((t + 1) & 1, ky, kx + 1, cc);
+      else if (more_ss) issue_b((t + 1) & 1, nky, 0, ncc);
+      if (more_ss) {
+        const int pc = 4 * kx + wave;
+        if (pc < SROWS / 16) issue_a((ss + 1) & 1, pc, nky, ncc);
+      }
+      const unsigned char* A = Abase + (ss & 1) * ASTRIP;
+      const unsigned char* Bt = Bbase + (t & 1) * BST + wcol * 64;
+      const int tap = ky * 3 + kx;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int s = wrow + i * 32 + r + kx;
+          const int fo = s * 64 + (((2 * ks + h) ^ ((s >> 2) & 3)) << 4);
+          ah[i] = *reinterpret_cast<const bf16x8*>(A + fo);
+          al[i] = *reinterpret_cast<const bf16x8*>(A + APL + fo);
+          if (any_masked && !((fmask[i] >> tap) & 1u)) {
+            const uintx4 z = {0u, 0u, 0u, 0u};
+            ah[i] = __builtin_bit_cast(bf16x8, z);
+            al[i] = __builtin_bit_cast(bf16x8, z);
+          }
+        }
+        const int bfo = ks ? bfo1 : bfo0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(Bt + j * 2048 + bfo);
+          bl[j] = *reinterpret_cast<const bf16x8*>(Bt + PLANE_B + j * 2048 + bfo);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    ky = nky;
+    cc = ncc;
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  planes_epilogue<TM, TN, GELU>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), m0, n0, wrow, wcol, lane);
+}
+
+template <int BN, bool GELU>
+int launch_strip2(const PlaneArgs& a, hipStream_t st) {
+  constexpr int LDS = 2 * (2 * 144 * 64) + 2 * (2 * BN * 64);
+  static_assert(LDS >= 4 * 32 * 36 * 4, "epilogue scratch");
+  const int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return FFSR_ELAUNCH;
+    attr_set = true;
+  }
+  FFSR_LAUNCH((conv3_strip_planes_kernel<BN, GELU>), dim3(tiles), dim3(256), LDS, st, a);
+  return ffsr_launch_status();
+}
+
+template <int BN>
+int launch_strip(PlaneArgs& a, hipStream_t st) {
+  if (a.act == FFSR_ACT_GELU) return launch_strip2<BN, true>(a, st);
+  if (a.act == FFSR_ACT_NONE) a.slope = 1.f;
+  else if (a.act == FFSR_ACT_RELU) a.slope = 0.f;
+  else if (a.act != FFSR_ACT_LRELU) return FFSR_EINVAL;
+  return launch_strip2<BN, false>(a, st);
+}
+
 // fp32 [M, C] (row stride ldx) -> bf16 hi / lo planes [M, ldp] (columns C..ldp-1 zero).  One thread = 8 columns.
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ hi,
                                                            unsigned short* __restrict__ lo, int ldp, long long M, int C) {
@@ -497,6 +682,11 @@ extern "C" int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, co
   hipStream_t st = (hipStream_t)stream;
   if (bm == 0) bm = 128;
   if (stages == 0) stages = 2;
+  if (stages == 4) {   // tap-strip variant: 3x3, stride 1, pad 1 only
+    FFSR_CHECK(KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && bm == 128 && (bn == 64 || bn == 128));
+    FFSR_CHECK((long long)B * H * W * Cp * 2 < (1ll << 40));
+    return bn == 64 ? launch_strip<64>(a, st) : launch_strip<128>(a, st);
+  }
   if (stages >= 10) { g_planes_sched = 0; stages -= 10; } else g_planes_sched = 1;   // stages + 10: burst-issue variant (diagnostic)
   switch ((bm / 128) * 10000 + bn * 10 + stages) {
     case 10642: return launch_planes<128, 64, 2>(a, st);

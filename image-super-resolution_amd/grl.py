@@ -80,7 +80,7 @@ class _Block:
         ops.grl_window_attn(qkv, 0, self.bw, self.lw, cat, 0, B, H, W, heads, hd, self.shift)
         ops.grl_stripe_attn(qkv, 3 * C // 2, anchor, self.b1, self.b2, self.l1, self.l2, cat, C // 2, B, H, W, heads, hd)
         a = ops.linear(cat, self.proj)
-        c2, att = self.cab(xm)
+        c2, att = self.cab(xp.reshape_map(B, H, W) if (pl and xp is not None) else xm)
         # y = x + LN(attn(x)) + CAB(x): the channel-attention scaling of CAB (c2 * att[batch]) rides in the LN kernel
         if not pl:
             y = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W)

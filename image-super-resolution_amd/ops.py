@@ -212,9 +212,20 @@ def zero_page(device) -> torch.Tensor:
     return _ZEROS[key]
 
 
-def planes_tile(M: int, N: int, K: int):
+STRIP3 = os.environ.get("FFSR_STRIP3", "1") != "0"   # FFSR_STRIP3=0: 3x3 convs stay on the per-tap tile kernel (A/B runs)
+
+
+def planes_tile(M: int, N: int, K: int, conv3: bool = False):
     """(bm, bn, stages) of the planes GEMM (measured on MI355X, tools/planes_bench.py): least padded N weighted by the
-    tile's efficiency (192 > 128 > 64 columns); 256-row tiles only pay on long-K shapes with many row tiles."""
+    tile's efficiency (192 > 128 > 64 columns); 256-row tiles only pay on long-K shapes with many row tiles.
+    conv3 (3x3, stride 1, pad 1): the tap-strip variant (stages 4; 64- / 128-column tiles) where it measured faster
+    (tools/strip_bench.py: N = 45 / 60 at Cin 180: 200 / 214 -> 134 / 153 us; 128 -> 128 at HR: 2394 -> 2309 us; with
+    N = 180 the 192-column per-tap tile stays ahead)."""
+    if conv3 and STRIP3 and M >= 16384:
+        if N <= 64:
+            return 128, 64, 4
+        if N <= 128 and K >= 512:
+            return 128, 128, 4
     best = None
     for bn, eff in ((192, 1.0), (128, 0.95), (64, 0.8)):
         cost = (N + bn - 1) // bn * bn / eff
@@ -276,7 +287,9 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
                  None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
                  0 if out_planes is None else out_planes.Cp, B, H, W, cv.N, 0 if out is None else ld(out), ldr, cv.KH,
                  cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope), float(cscale), float(rscale),
-                 *((bm or 128, bn, stages) if bn else planes_tile(B * Ho * Wo, cv.N, cv.KH * cv.KW * x.Cp)), _stream())
+                 *((bm or 128, bn, stages) if bn else
+                   planes_tile(B * Ho * Wo, cv.N, cv.KH * cv.KW * x.Cp,
+                               cv.KH == 3 and cv.KW == 3 and cv.stride == 1 and cv.pad == 1)), _stream())
     else:
         ldi = ld(x)
         assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"

@@ -58,7 +58,9 @@ int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, 
  * [n_rows_padded, KH*KW*Cp] (tap-major, Cp channels per tap, zero padded; n_rows_padded % bn == 0).  Outputs: fp32
  * `out` (may be NULL) and / or bf16 planes out_hi / out_lo [M, ldp] (may be NULL; ldp = N rounded up to 32, columns
  * >= N are written as zeros) for a following ffsr_conv2d_planes.  act: 0 none, 1 GELU, 2 ReLU, 3 LeakyReLU only.
- * bm x bn = 128 / 256 rows x 64 / 128 / 192 / 256 columns tile (bm 0 = 128); stages = LDS pipeline depth (0 = default).  Replaces the same reference calls as
+ * bm x bn = 128 / 256 rows x 64 / 128 / 192 / 256 columns tile (bm 0 = 128); stages = LDS pipeline depth (0 = default:
+ * 2; 2 or 3), or 4 = the tap-strip variant for 3x3 / stride 1 / pad 1 convolutions (bm 128, bn 64 or 128 only): one
+ * staged strip of A rows serves the three horizontal taps.  Replaces the same reference calls as
  * ffsr_conv2d_f32 wherever the producer of the input can emit planes (LayerNorm, attention, gates, a previous GEMM). */
 int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, const void* wgt_hi, const void* wgt_lo,
                        int n_rows_padded, const void* zeros, const float* bias, float* out, const float* res,

@@ -71,6 +71,24 @@ def test_conv2d_planes_vs_torch_and_vs_f32_input_kernel(ops, E, B, H, W, Cin, N,
         close(got, same, 2e-6, "planes vs fp32-input kernel")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,N,act,bn", [
+    (2, 21, 37, 180, 60, 1, 64), (1, 18, 22, 180, 45, 0, 64), (3, 9, 130, 64, 128, 1, 128), (1, 33, 35, 128, 128, 0, 128),
+    (2, 20, 24, 60, 180, 3, 64), (1, 16, 128, 32, 200, 2, 128), (1, 3, 5, 180, 60, 0, 64), (2, 1, 300, 45, 64, 0, 64),
+])
+def test_conv3x3_tap_strip_variant(ops, E, B, H, W, Cin, N, act, bn):
+    """stages = 4: the 3x3 kernel whose horizontal taps share one staged A strip.  Tiles that wrap image rows, image
+    borders inside a tile, several images in one tile, a one-row image; against torch and against the per-tap kernel
+    (same products; the K steps are accumulated in a different order)."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(N, Cin, 3, 3, seed=2, scale=1 / math.sqrt(Cin * 9)), rnd(N, seed=3)
+    want = ACT[act](F.conv2d(x, w, b, padding=1))
+    cv = ops.pack_conv(w, b, DEV, pad=1)
+    xp = ops.split_planes(E.nchw_to_map(x, DEV))
+    got = ops.conv2d(xp, cv, act=act, slope=0.2, bm=128, bn=bn, stages=4)
+    close(E.map_to_nchw(got), want, 2e-4, "strip vs torch")
+    ref = ops.conv2d(xp, cv, act=act, slope=0.2, bm=128, bn=bn, stages=2)
+    close(got, ref, 2e-6, "strip vs per-tap kernel")
+
+
 def test_conv2d_planes_epilogue_and_plane_output(ops, E):
     B, H, W, C, N = 2, 10, 13, 64, 180
     x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, 1, 1, seed=2, scale=0.1), rnd(N, seed=3)
