@@ -422,6 +422,34 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
   // ---- epilogue.  Lean path (no PixelShuffle): one pointer per lane, compile-time row offsets, the activation switch
   // hoisted out of the element loop; rows are bounds-checked only in the last row tile.
   const bool full_rows = m0 + BM <= p.M;
+  if constexpr (TN == 2) {
+    if (p.shuffle == 3) {
+      // SimpleGate fused into the store (nafnet_arch.py:21-24, x1 * x2 over the channel halves): the host packs the weight
+      // rows so that a wave's two 32-column tiles hold x1[j..j+31] and x2[j..j+31]; the product is lane-local.
+      // out / res / cvec / rvec have N / 2 columns.
+      const int na = n0 + wcol + r, no = (n0 + wcol) / 2 + r;
+      if (na >= p.N) return;   // (N % 64 == 0: whole pairs)
+      const float ba = p.bias ? p.bias[na] : 0.f, bb = p.bias ? p.bias[na + 32] : 0.f;
+      const float cs = (p.cvec ? p.cvec[no] : 1.f) * p.cscale;
+      const float rs = (p.rvec ? p.rvec[no] : 1.f) * p.rscale;
+#pragma unroll
+      for (int im = 0; im < TM; ++im) {
+        const int mrow = m0 + wrow + im * 32 + 4 * h;
+        float* op = p.out + (size_t)mrow * p.ldo + no;
+        const float* rp = p.res ? p.res + (size_t)mrow * p.ldr + no : nullptr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          if (full_rows || mrow + dr < p.M) {
+            float o = (acc[im][0][e] + ba) * (acc[im][1][e] + bb) * cs;
+            if (rp) o += rp[dr * p.ldr] * rs;
+            op[dr * p.ldo] = o;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
     const int n = n0 + wcol + jn * 32 + r;
@@ -555,7 +583,7 @@ extern "C" int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const voi
   FFSR_CHECK(Cin > 0 && (Cin & 3) == 0 && (ldi & 3) == 0 && ldi >= Cin);
   FFSR_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)wgt_hi & 15) == 0 && ((uintptr_t)wgt_lo & 15) == 0 &&
              ((uintptr_t)zeros & 15) == 0);
-  FFSR_CHECK(shuffle == 0 || (shuffle == 2 && (N & 3) == 0));
+  FFSR_CHECK(shuffle == 0 || (shuffle == 2 && (N & 3) == 0) || (shuffle == 3 && (N & 63) == 0 && bn == 128 && act == FFSR_ACT_NONE));
   FFSR_CHECK(!akscale || (KH * KW == 1 && akrows > 0 && ((uintptr_t)akscale & 15) == 0));
   FFSR_CHECK(bn == 32 || bn == 64 || bn == 128);
   const int Ktot = KH * KW * Cin;

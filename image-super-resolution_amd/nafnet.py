@@ -24,6 +24,8 @@ class _Block:
         self.conv3 = ops.pack_conv(sd[p + "conv3.weight"], sd[p + "conv3.bias"], device)
         self.sca = ops.pack_conv(sd[p + "sca.1.weight"], sd[p + "sca.1.bias"], device)
         self.conv4 = ops.pack_conv(sd[p + "conv4.weight"], sd[p + "conv4.bias"], device)
+        # shallow levels: SimpleGate rides in conv4's store (weight rows packed as interleaved 32-channel pairs)
+        self.conv4g = ops.pack_conv(sd[p + "conv4.weight"], sd[p + "conv4.bias"], device, gate_pairs=True) if (c < 256 and c % 32 == 0) else None
         self.conv5 = ops.pack_conv(sd[p + "conv5.weight"], sd[p + "conv5.bias"], device)
         self.beta = dev(sd[p + "beta"].reshape(-1), device)
         self.gamma = dev(sd[p + "gamma"].reshape(-1), device)
@@ -38,8 +40,13 @@ class _Block:
         g, pooled = ops.dw3x3_gate_pool(t, self.dw)              # SimpleGate + global average pool
         sca = ops.linear(pooled, self.sca)                       # [B, c] channel attention
         y = ops.conv2d(g, self.conv3, akscale=sca.contiguous(), res=x, cvec=self.beta)   # x + conv3(g*sca)*beta
-        t = ops.conv2d(ops.layernorm(y, *self.n2, eps=1e-6, out_planes=True if pl else None, want_f32=not pl), self.conv4)
-        g = ops.mul_add(t[..., :c], t[..., c:])                  # SimpleGate
+        t = ops.layernorm(y, *self.n2, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
+        B, H, W, _ = y.shape
+        if self.conv4g is not None and ops.GEMM_MODE == "bf16x3" and ops.GATE_FUSED and B * H * W > 64 * 24:
+            g = ops.conv2d(t, self.conv4g, gate=True)            # conv4 + SimpleGate in one kernel
+        else:
+            t = ops.conv2d(t, self.conv4)
+            g = ops.mul_add(t[..., :c], t[..., c:])              # SimpleGate
         return ops.conv2d(g, self.conv5, res=y, cvec=self.gamma)
 
 

@@ -169,12 +169,21 @@ class Conv:
 
 
 def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
-              in_perm=None) -> Conv:
+              in_perm=None, gate_pairs=False) -> Conv:
     """w: [N, Cin, KH, KW] (nn.Conv2d) or [N, K] (nn.Linear).  cin_pad: padded channel count of the input map.
     Load-time weight preparation (layout change, zero padding, bf16 hi/lo split): done with torch ops on `device`."""
     w = w.detach().float().to(device)
     if w.dim() == 2:
         w = w[:, :, None, None]
+    if gate_pairs:
+        # SimpleGate fused into the GEMM store (conv2d(..., gate=True)): output column q of the packed matrix is
+        # x1[32 b + i] for q = 64 b + i and x2[32 b + i] for q = 64 b + 32 + i (i < 32), x1 / x2 = the channel halves
+        c = w.shape[0] // 2
+        assert w.shape[0] == 2 * c and c % 32 == 0
+        q = torch.arange(2 * c, device=w.device)
+        perm = (q // 64) * 32 + (q % 32) + (q % 64 >= 32) * c
+        w = w[perm]
+        b = None if b is None else b.detach().to(device)[perm]
     N, Cin, KH, KW = w.shape
     Cp = cin_pad if cin_pad is not None else pad4(Cin)
     assert Cp >= Cin and Cp % 4 == 0
@@ -212,6 +221,7 @@ def zero_page(device) -> torch.Tensor:
     return _ZEROS[key]
 
 
+GATE_FUSED = os.environ.get("FFSR_GATE_FUSED", "1") != "0"   # FFSR_GATE_FUSED=0: NAFNet's conv4 and SimpleGate stay separate (A/B runs)
 STRIP3 = os.environ.get("FFSR_STRIP3", "1") != "0"   # FFSR_STRIP3=0: 3x3 convs stay on the per-tap tile kernel (A/B runs)
 
 
@@ -243,8 +253,11 @@ PLANES_AUTO = os.environ.get("FFSR_PLANES", "1") != "0"   # FFSR_PLANES=0: every
 
 def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
            res: Optional[torch.Tensor] = None, cvec=None, rvec=None, cscale=1.0, rscale=1.0, shuffle=0,
-           akscale: Optional[torch.Tensor] = None, tile_hint=0, out_planes=None, want_f32=True, bm=0, bn=0, stages=0):
+           akscale: Optional[torch.Tensor] = None, tile_hint=0, out_planes=None, want_f32=True, bm=0, bn=0, stages=0,
+           gate=False):
     """x [B,H,W,>=Cin] fp32 map or Planes -> [B,Ho,Wo,N] (or [B,2Ho,2Wo,N/4] with shuffle=2).
+    gate=True (split-bf16 mode, fp32 input, weights packed with gate_pairs=True): the store multiplies the two channel
+    halves (NAFNet's SimpleGate) -> [B,Ho,Wo,N/2]; res / cvec / rvec refer to the N/2 output channels.
     out_planes: True / a Planes object -> also emit the result as bf16 hi / lo planes (returned as (out, planes), or
     only the planes when want_f32 is False)."""
     B, H, W, _ = x.shape
@@ -252,9 +265,15 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
     Wo = (W + 2 * cv.pad - cv.KW) // cv.stride + 1
     if shuffle:
         oshape = (B, 2 * Ho, 2 * Wo, cv.N // 4)
+    elif gate:
+        oshape = (B, Ho, Wo, cv.N // 2)
     else:
         oshape = (B, Ho, Wo, cv.N)
     is_planes = isinstance(x, Planes)
+    if gate:
+        if is_planes or GEMM_MODE != "bf16x3" or shuffle or act != ACT_NONE or cv.N % 64 or B * Ho * Wo <= 64 * 24:
+            raise ValueError("gate=True needs an fp32 map input, the split-bf16 mode, no activation and N % 64 == 0")
+        shuffle, tile_hint = 3, 128           # store mode 3 of ffsr_conv2d_bf16x3
     if (not is_planes and PLANES_AUTO and GEMM_MODE == "bf16x3" and not shuffle and akscale is None and tile_hint == 0
             and act in PLANES_ACTS and cv.KH * cv.KW > 1 and cv.stride == 1 and cv.Cin_true >= 32 and cv.N > 64 and B * Ho * Wo >= 16384):
         # long-K conv on an fp32 map: one extra split pass (read + write of the input) buys the ~1.5x faster planes GEMM

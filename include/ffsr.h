@@ -45,7 +45,10 @@ int ffsr_conv2d_f32(const float* in, const float* wgt, const float* bias, float*
  * ~1e-5 relative per product).  wgt_hi / wgt_lo: bf16 planes [n_rows_padded, ldw] of the weight matrix, pre-split at
  * pack time (hi = bf16(w), lo = bf16(w - hi)) and zero padded to n_rows_padded % bn == 0 rows and ldw % 32 == 0
  * columns (n_rows_padded % 128 == 0); zeros: >= 64 bytes of zeros (read for padding taps / rows); bn = column tile,
- * 32 (N <= 32), 64 or 128. */
+ * 32 (N <= 32), 64 or 128.  shuffle = 3 (bn 128, act none, N % 64 == 0) fuses NAFNet's SimpleGate (nafnet_arch.py:21-24,
+ * :127-129) into the store: out[pix, j] = res * rvec * rscale + x1[j] * x2[j] * cvec[j] * cscale with N / 2 output
+ * columns, where the weight / bias rows are packed so that GEMM column 64 b + i is x1[32 b + i] and 64 b + 32 + i is
+ * x2[32 b + i] (i < 32; x1 / x2 = the two channel halves of the convolution output). */
 int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, int ldw, int n_rows_padded,
                        const float* zeros, const float* bias, float* out, const float* res, const float* cvec,
                        const float* rvec, const float* akscale, int B, int H, int W, int Cin, int ldi, int N, int ldo,

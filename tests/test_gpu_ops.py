@@ -77,6 +77,25 @@ def test_conv2d_epilogue_residual_scale_shuffle_akscale(ops, E):
     close(E.map_to_nchw(got), want, gemm_tol(ops), "shuffle")
 
 
+@pytest.mark.parametrize("B,H,W,c", [(1, 40, 52, 64), (2, 33, 31, 128), (1, 64, 64, 32)])
+def test_conv2d_fused_simple_gate(ops, E, B, H, W, c):
+    """conv (c -> 2c) + SimpleGate (x1 * x2, nafnet_arch.py:21-24) + scaled residual in one kernel (store mode 3)."""
+    if ops.GEMM_MODE != "bf16x3":
+        pytest.skip("the gate store exists on the split-bf16 kernel only")
+    x, w, b = rnd(B, c, H, W, seed=1), rnd(2 * c, c, 1, 1, seed=2, scale=1 / math.sqrt(c)), rnd(2 * c, seed=3)
+    res, cvec = rnd(B, c, H, W, seed=4), rnd(c, seed=5)
+    t = F.conv2d(x, w, b)
+    want = res + t[:, :c] * t[:, c:] * cvec[None, :, None, None]
+    cv = ops.pack_conv(w, b, DEV, gate_pairs=True)
+    got = ops.conv2d(E.nchw_to_map(x, DEV), cv, gate=True, res=E.nchw_to_map(res, DEV), cvec=cvec.to(DEV))
+    assert tuple(got.shape) == (B, H, W, c)
+    close(E.map_to_nchw(got), want, 2e-4, "fused gate")
+    plain = ops.pack_conv(w, b, DEV)
+    t2 = ops.conv2d(E.nchw_to_map(x, DEV), plain, tile_hint=128)
+    g2 = ops.mul_add(t2[..., :c], t2[..., c:])
+    close(ops.conv2d(E.nchw_to_map(x, DEV), cv, gate=True), g2, 1e-6, "fused vs separate gate")
+
+
 def test_conv2d_strided_views(ops, E):
     """inputs / outputs that are channel slices of wider buffers (dense-concat buffers of DRCT / hierarchical fusion)"""
     P, wide = 200, 308
