@@ -38,7 +38,7 @@ def set_gemm_mode(mode: str):
 
 
 # bench.py sets this to a list to time every conv/GEMM launch with events on the launch stream:
-# entries (start_event, end_event, algorithmic flops = 2 * M * N * KH*KW*Cin with the UNPADDED Cin)
+# entries (start_event, end_event, algorithmic flops = 2 * M * N * KH*KW*Cin with the UNPADDED Cin, shape + kernel kind, bytes)
 CONV_PROFILE = None
 
 
@@ -296,19 +296,20 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    kernel_kind = 0      # for CONV_PROFILE: 0 fp32-input kernel, 1 planes tile kernel, 2 planes tap-strip kernel
     if is_planes:
         assert x.Cp == cv.Cp32 and x.C == cv.Cin_true, f"planes input {x.shape} (Cp {x.Cp}) vs conv Cin {cv.Cin_true}"
         assert not shuffle and akscale is None and act in PLANES_ACTS
         if out_planes is not None:
             assert out_planes.shape == oshape
+        tile = (bm or 128, bn, stages) if bn else planes_tile(B * Ho * Wo, cv.N, cv.KH * cv.KW * x.Cp,
+                                                              cv.KH == 3 and cv.KW == 3 and cv.stride == 1 and cv.pad == 1)
+        kernel_kind = 2 if tile[2] == 4 else 1
         hip.call("ffsr_conv2d_planes", _ptr(x.hi), _ptr(x.lo), x.Cp, _ptr(cv.phi), _ptr(cv.plo), cv.phi.shape[0],
                  _ptr(zero_page(dev_)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
                  None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
                  0 if out_planes is None else out_planes.Cp, B, H, W, cv.N, 0 if out is None else ld(out), ldr, cv.KH,
-                 cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope), float(cscale), float(rscale),
-                 *((bm or 128, bn, stages) if bn else
-                   planes_tile(B * Ho * Wo, cv.N, cv.KH * cv.KW * x.Cp,
-                               cv.KH == 3 and cv.KW == 3 and cv.stride == 1 and cv.pad == 1)), _stream())
+                 cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope), float(cscale), float(rscale), *tile, _stream())
     else:
         ldi = ld(x)
         assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"
@@ -330,7 +331,7 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * B * Ho * Wo * cv.N * cv.KH * cv.KW * cv.Cin_true,
-                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH, int(is_planes)),
+                     (B * Ho * Wo, cv.N, cv.KH * cv.KW * cv.Cin, cv.KH, kernel_kind),
                      4.0 * (B * H * W * cv.Cin_true + cv.N * cv.KH * cv.KW * cv.Cin_true
                             + B * Ho * Wo * cv.N * (2 if res is not None else 1))))
     if out_planes is not None:
