@@ -430,7 +430,7 @@ int launch_planes(PlaneArgs& a, hipStream_t st) {
 // down by kx: one 130-row strip (144 staged) per (ky, 32-channel chunk) serves kx = 0, 1, 2 through fragment reads at row
 // offsets 0 / 1 / 2 -- 9 pieces per plane instead of 24.  What a shifted read picks up across an image border (the
 // neighbouring pixel of the previous / next image row) is zeroed in the fragment registers from the per-row tap mask.
-template <int BN, bool GELU>
+template <int BN, bool GELU, int SCHED>
 __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64, NW = 4;
   constexpr int SROWS = 144;                                  // 130 used, staged in 16-row pieces
@@ -458,16 +458,19 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
   const ptrdiff_t lo_delta = reinterpret_cast<const unsigned char*>(p.a_lo) - reinterpret_cast<const unsigned char*>(p.a_hi);
 
   // strip piece pc (16 rows) of super-step (ky, cc) -> strip buffer `buf`: strip row s holds input pixel m0 - 1 + s + (ky - 1) W
-  auto issue_a = [&](int buf, int pc, int ky, int cc) {
+  auto issue_a1 = [&](int buf, int pc, int ky, int cc, int plane) {
     const int srow = 16 * pc + lrow;
     const long long q = (long long)m0 - 1 + srow + (long long)(ky - 1) * p.W;
     const int chunk = (lane & 3) ^ ((srow >> 2) & 3);
     const bool ok = q >= 0 && q < npix;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(p.a_hi) + ((size_t)(ok ? q : 0) * p.Cp + cc * 32 + chunk * 8) * 2;
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(p.zeros);
-    unsigned char* dst = Abase + buf * ASTRIP + pc * 1024;
-    __builtin_amdgcn_global_load_lds(ok ? src : zp, (lds_ptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(ok ? src + lo_delta : zp, (lds_ptr_t)(dst + APL), 16, 0, 0);
+    if (plane) src += lo_delta;
+    unsigned char* dst = Abase + buf * ASTRIP + pc * 1024 + plane * APL;
+    __builtin_amdgcn_global_load_lds(ok ? src : reinterpret_cast<const unsigned char*>(p.zeros), (lds_ptr_t)dst, 16, 0, 0);
+  };
+  auto issue_a = [&](int buf, int pc, int ky, int cc) {
+    issue_a1(buf, pc, ky, cc, 0);
+    issue_a1(buf, pc, ky, cc, 1);
   };
   unsigned b_off[NB];
 #pragma unroll
@@ -476,14 +479,17 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
     b_off[j] = (unsigned)((n0 + row) * (p.nk * 32) + chunk * 8) * 2u;
   }
+  auto issue_b1 = [&](int buf, unsigned koff, int j, int plane) {
+    unsigned char* dst = Bbase + buf * BST + (wave + NW * j) * 1024 + plane * PLANE_B;
+    const size_t o = (size_t)b_off[j] + koff;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(plane ? p.w_lo : p.w_hi) + o, (lds_ptr_t)dst, 16, 0, 0);
+  };
   auto issue_b = [&](int buf, int ky, int kx, int cc) {
     const unsigned koff = (unsigned)(((ky * 3 + kx) * cpt + cc) * 64);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      unsigned char* dst = Bbase + buf * BST + (wave + NW * j) * 1024;
-      const size_t o = (size_t)b_off[j] + koff;
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(p.w_hi) + o, (lds_ptr_t)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(p.w_lo) + o, (lds_ptr_t)(dst + PLANE_B), 16, 0, 0);
+      issue_b1(buf, koff, j, 0);
+      issue_b1(buf, koff, j, 1);
     }
   };
 
@@ -535,11 +541,22 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
       __builtin_amdgcn_s_barrier();   // this step's strip / weights have landed; the buffers refilled below are no longer read
       const int t = 3 * ss + kx;
       // next step's weights; the next super-step's strip is fetched in thirds (pieces 0-3, 4-7, 8) while this one is consumed
-      if (kx < 2) issue_b((t + 1) & 1, ky, kx + 1, cc);
-      else if (more_ss) issue_b((t + 1) & 1, nky, 0, ncc);
-      if (more_ss) {
-        const int pc = 4 * kx + wave;
-        if (pc < SROWS / 16) issue_a((ss + 1) & 1, pc, nky, ncc);
+      const bool has_b = kx < 2 || more_ss;
+      const int bky = kx < 2 ? ky : nky, bkx = kx < 2 ? kx + 1 : 0, bcc = kx < 2 ? cc : ncc;
+      const unsigned bkoff = (unsigned)(((bky * 3 + bkx) * cpt + bcc) * 64);
+      const int apc = 4 * kx + wave;
+      const bool has_a = more_ss && apc < SROWS / 16;
+      constexpr int LOADS = 2 * NB + 2;
+      auto issue_piece = [&](int idx) {      // 0 .. 2 NB - 1: weight pieces; 2 NB, 2 NB + 1: the strip piece's planes
+        if (idx < 2 * NB) {
+          if (has_b) issue_b1((t + 1) & 1, bkoff, idx >> 1, idx & 1);
+        } else if (has_a) {
+          issue_a1((ss + 1) & 1, apc, nky, ncc, idx - 2 * NB);
+        }
+      };
+      if constexpr (SCHED == 0) {
+#pragma unroll
+        for (int idx = 0; idx < LOADS; ++idx) issue_piece(idx);
       }
       const unsigned char* A = Abase + (ss & 1) * ASTRIP;
       const unsigned char* Bt = Bbase + (t & 1) * BST + wcol * 64;
@@ -565,14 +582,24 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
           bh[j] = *reinterpret_cast<const bf16x8*>(Bt + j * 2048 + bfo);
           bl[j] = *reinterpret_cast<const bf16x8*>(Bt + PLANE_B + j * 2048 + bfo);
         }
+        static_for<0, TM * TN>([&](auto tc) {
+          constexpr int tt = decltype(tc)::value, i = tt / TN, j = tt % TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (SCHED == 1) {
+            // one LDS-DMA piece after each MFMA triple instead of a burst behind the barrier
+            constexpr int GROUPS = 2 * TM * TN;
+            const int g = ks * TM * TN + tt;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int idx = 0; idx < LOADS; ++idx)
+              if (idx * GROUPS / LOADS == g) issue_piece(idx);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            constexpr int c0 = pieces_in_group(tt, GROUPS, LOADS), c1 = pieces_in_group(TM * TN + tt, GROUPS, LOADS);
+            if (ks == 0) { if constexpr (c0 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c0, 0); }
+            else { if constexpr (c1 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c1, 0); }
           }
+        });
       }
     }
     ky = nky;
@@ -583,20 +610,27 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
   planes_epilogue<TM, TN, GELU>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), m0, n0, wrow, wcol, lane);
 }
 
-template <int BN, bool GELU>
-int launch_strip2(const PlaneArgs& a, hipStream_t st) {
+template <int BN, bool GELU, int SCHED>
+int launch_strip3(const PlaneArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * (2 * 144 * 64) + 2 * (2 * BN * 64);
   static_assert(LDS >= 4 * 32 * 36 * 4, "epilogue scratch");
   const int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU, SCHED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return FFSR_ELAUNCH;
     attr_set = true;
   }
-  FFSR_LAUNCH((conv3_strip_planes_kernel<BN, GELU>), dim3(tiles), dim3(256), LDS, st, a);
+  FFSR_LAUNCH((conv3_strip_planes_kernel<BN, GELU, SCHED>), dim3(tiles), dim3(256), LDS, st, a);
   return ffsr_launch_status();
+}
+// Measured (tools/strip_bench.py): with the 64-column tile (6 MFMAs per K half) the burst of 4 pieces behind the barrier is
+// faster than one piece per MFMA triple (N 45: 132 vs 147 us, N 60: 156 vs 161, 64 -> 64 at HR/2: 187 vs 201); with the
+// 128-column tile the interleaved issue is marginally ahead (212 vs 216 us, 2274 vs 2284 us).
+template <int BN, bool GELU>
+int launch_strip2(const PlaneArgs& a, hipStream_t st) {
+  return launch_strip3<BN, GELU, (BN >= 128 ? 1 : 0)>(a, st);
 }
 
 template <int BN>
