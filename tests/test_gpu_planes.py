@@ -180,11 +180,32 @@ def test_planes_entry_points_reject_bad_arguments(ops, pkg):
     ok = out.clone()
     out.fill_(5.0)
     for bad in (dict(Cp=180), dict(bn=96), dict(bm=64), dict(stages=7), dict(act=4), dict(act=5),
-                dict(hi=xp.hi.data_ptr(), ldp=180), dict(a_hi=xp.hi.reshape(-1)[1:])):
+                dict(hi=xp.hi.data_ptr(), ldp=180), dict(a_hi=xp.hi.reshape(-1)[1:]),
+                dict(stages=4, bn=64)):                                  # the tap-strip variant is for 3x3 / stride 1 / pad 1 only
         with pytest.raises(hip.FfsrError, match="invalid argument"):
             call(**bad)
     torch.cuda.synchronize()
     assert (out == 5.0).all() and not (ok == 5.0).all()
+    # SimpleGate store mode (shuffle = 3) of the split-bf16 kernel: 128-column tile, no activation, N % 64 == 0
+    xf = rnd(1, 40, 52, 64, seed=3).to(DEV)
+    cg = ops.pack_conv(rnd(128, 64, 1, 1, seed=4), rnd(128, seed=5), DEV, gate_pairs=True)
+    og = torch.full((1, 40, 52, 64), 5.0, device=DEV)
+
+    def gate_call(bn=128, act=0, N=128):
+        hip.call("ffsr_conv2d_bf16x3", xf.data_ptr(), cg.whi.data_ptr(), cg.wlo.data_ptr(), cg.whi.shape[1], cg.whi.shape[0],
+                 z.data_ptr(), cg.bias.data_ptr(), og.data_ptr(), None, None, None, None, 1, 40, 52, 64, 64, N, 64, 0, 1, 1, 1,
+                 0, 0, act, 0.0, 1.0, 1.0, 3, 0, bn, torch.cuda.current_stream().cuda_stream)
+
+    for bad in (dict(bn=64), dict(act=1), dict(N=96)):
+        with pytest.raises(hip.FfsrError, match="invalid argument"):
+            gate_call(**bad)
+    torch.cuda.synchronize()
+    assert (og == 5.0).all()
+    gate_call()
+    torch.cuda.synchronize()
+    assert not (og == 5.0).any()
+    with pytest.raises(ValueError):
+        ops.conv2d(ops.split_planes(xf), cg, gate=True)                    # host-side guard: the gate store takes an fp32 map
     with pytest.raises(hip.FfsrError, match="invalid argument"):           # LayerNorm planes need the vectorised path
         hip.call("ffsr_layernorm_planes_f32", x.data_ptr(), 180, x.data_ptr(), x.data_ptr(), 1e-5, None, 0, xp.hi.data_ptr(),
                  xp.lo.data_ptr(), 160, None, 0, None, 0, None, 0, 64, 180, torch.cuda.current_stream().cuda_stream)
