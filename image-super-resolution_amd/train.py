@@ -1,0 +1,85 @@
+"""Optimiser side of the reference's cached-feature training step on the HIP kernels of ffsr_train.hip.
+
+Mirrors, for ONE flat fp32 parameter buffer, what ``train_epoch_cached`` (train.py:251-384) does around ``loss.backward()``:
+``sr.clamp(0, 1)`` + ``L1Loss`` + the division by ``accumulation_steps`` (:326-336), ``clip_grad_norm_`` (:347-352),
+``optimizer.step()`` of ``torch.optim.AdamW`` (:354) and ``EMAModel.update`` (:358-359, checkpoint_manager.py:349-356).
+The backward pass of the fusion network itself is NOT built yet: ``FusionOptimizer.grad`` is the flat gradient buffer a
+future backward (or a test) fills.  No CPU fallback: the calls raise without the HIP library.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+from . import hip
+from .ops import _mat, _ptr, _stream
+
+N_PARTIAL = 1024
+
+
+def l1_clamp_loss(sr: torch.Tensor, hr: torch.Tensor, accumulation_steps: int = 1, need_grad: bool = True):
+    """sr, hr: channels-last maps [B,H,W,C] (row strides may be padded).  Returns (loss [1] on the device =
+    mean|clamp(sr,0,1) - hr| / accumulation_steps, d loss / d sr with sr's shape, or None)."""
+    _, M, C, lds = _mat(sr)
+    _, M2, C2, ldh = _mat(hr)
+    if (M, C) != (M2, C2):
+        raise ValueError(f"sr {tuple(sr.shape)} and hr {tuple(hr.shape)} differ")
+    grad = torch.empty_like(sr) if need_grad else None
+    part = torch.empty(N_PARTIAL, device=sr.device)
+    loss = torch.empty(1, device=sr.device)
+    hip.call("ffsr_l1_clamp_loss_f32", _ptr(sr), lds, _ptr(hr), ldh, _ptr(grad), 0 if grad is None else _mat(grad)[3],
+             _ptr(part), N_PARTIAL, _ptr(loss), M, C, 1.0 / accumulation_steps, _stream())
+    return loss, grad
+
+
+class FusionOptimizer:
+    """AdamW + gradient clipping + EMA over the trainable tensors of a state_dict, held in one flat device buffer.
+    Defaults = configs/train_config.yaml of the reference (lr 2e-4, weight decay 1e-4, betas (0.9, 0.999), eps 1e-8,
+    gradient_clip 1.0, EMA decay 0.999)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], device, lr=2e-4, betas: Tuple[float, float] = (0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-4, max_norm=1.0, ema_decay=0.999):
+        self.device = torch.device(device)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_norm, self.ema_decay = max_norm, ema_decay
+        self.layout = []
+        off = 0
+        for k, v in params.items():
+            self.layout.append((k, tuple(v.shape), off, v.numel()))
+            off += v.numel()
+        self.n = off
+        self.param = torch.empty(off, device=self.device)
+        for (k, shape, o, n) in self.layout:
+            self.param[o:o + n] = params[k].detach().reshape(-1).to(self.device, torch.float32)
+        self.grad = torch.zeros_like(self.param)
+        self.exp_avg = torch.zeros_like(self.param)
+        self.exp_avg_sq = torch.zeros_like(self.param)
+        self.ema = self.param.clone() if ema_decay is not None else None       # EMAModel.__init__: shadow = clone
+        self.step_count = 0
+        self._part = torch.empty(N_PARTIAL, device=self.device)
+        self._sumsq = torch.zeros(1, device=self.device)
+
+    def views(self, buf: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+        """name -> view into the flat buffer (default: the parameters)"""
+        buf = self.param if buf is None else buf
+        return {k: buf[o:o + n].reshape(shape) for (k, shape, o, n) in self.layout}
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def grad_norm(self) -> torch.Tensor:
+        """total 2-norm of the gradient (device scalar), as clip_grad_norm_ returns it"""
+        hip.call("ffsr_sumsq_f32", _ptr(self.grad), self.n, _ptr(self._part), N_PARTIAL, _ptr(self._sumsq), _stream())
+        return self._sumsq.sqrt()
+
+    def step(self, lr: float = None):
+        """clip_grad_norm_ -> AdamW.step -> EMA.update, two launches + one fused pass, no host synchronisation"""
+        self.step_count += 1
+        clip = self.max_norm is not None and self.max_norm > 0
+        if clip:
+            hip.call("ffsr_sumsq_f32", _ptr(self.grad), self.n, _ptr(self._part), N_PARTIAL, _ptr(self._sumsq), _stream())
+        hip.call("ffsr_adamw_ema_f32", _ptr(self.param), _ptr(self.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                 _ptr(self.ema), self.n, _ptr(self._sumsq) if clip else None, float(self.max_norm or 0.0),
+                 float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                 float(self.weight_decay), self.step_count, float(self.ema_decay or 0.0), _stream())

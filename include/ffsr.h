@@ -224,6 +224,25 @@ int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, co
 int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12, int ld,
                       float* out, int ldo, long long M, void* stream);
 
+/* ---- optimiser side of the cached-feature training step (the backward kernels of the fusion phases are
+ * not built yet).  Flat fp32 buffers, deterministic two-stage reductions; `partial` is caller-owned scratch of at least
+ * 1024 floats (n_partial says how many).
+ *
+ * loss[0] = loss_scale * mean |clamp(sr, 0, 1) - hr| over M rows x C columns; grad (may be NULL) = d loss / d sr =
+ * loss_scale / (M C) * sign(clamp(sr) - hr) where 0 <= sr <= 1, else 0.  Replaces train.py:326-336 (clamp, L1Loss
+ * perceptual_loss.py:68-100, the division by accumulation_steps = loss_scale) and their autograd backward. */
+int ffsr_l1_clamp_loss_f32(const float* sr, int ldsr, const float* hr, int ldhr, float* grad, int ldg, float* partial,
+                           int n_partial, float* loss, long long M, int C, float loss_scale, void* stream);
+/* out[0] = sum x[i]^2 (the squared total norm of torch.nn.utils.clip_grad_norm_, train.py:347-352). */
+int ffsr_sumsq_f32(const float* x, long long n, float* partial, int n_partial, float* out, void* stream);
+/* One fused pass over the flat parameter buffer: gradient clipping (coef = min(1, max_norm / (sqrt(grad_sumsq[0]) + 1e-6));
+ * grad_sumsq NULL or max_norm <= 0: none), torch.optim.AdamW's update for step number `step` (>= 1; decoupled weight
+ * decay, bias corrections computed on the host in double) and EMAModel.update (ema may be NULL):
+ * train.py:347-359, checkpoint_manager.py:349-356. */
+int ffsr_adamw_ema_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, long long n,
+                       const float* grad_sumsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, float ema_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
