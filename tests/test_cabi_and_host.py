@@ -106,6 +106,41 @@ def test_shapes_only_template_and_lazy_defaults(tmp_path):
     assert torch.equal(got["drct"]["conv_first.bias"], small["drct"]["conv_first.bias"])
 
 
+def test_cached_feature_format_roundtrip(tmp_path):
+    """the reference's 3-part cache files (extract_features_balanced.py:162-183, extract_mamba_features.py:226-237) and
+    CachedSRDataset.__getitem__'s view of them (cached_dataset.py:135-226), incl. the zero fallback without a mamba part"""
+    C = mod("cache")
+    g = torch.Generator().manual_seed(0)
+    h, w = 8, 12
+    lr, hr = torch.rand(3, h, w, generator=g), torch.rand(3, 4 * h, 4 * w, generator=g)
+    outs = {k: torch.rand(1, 3, 4 * h, 4 * w, generator=g) for k in ("drct", "grl", "nafnet", "mamba")}
+    feats = {k: torch.randn(1, 64 if k == "nafnet" else 180, h, w, generator=g) for k in outs}
+    C.save_entry(tmp_path, "0001", lr, hr, outs, feats)
+    C.save_entry(tmp_path, "0002", lr, hr, outs, feats, parts=("drct", "rest"))
+    C.save_entry(tmp_path, "0003", lr, hr, outs, feats, parts=("drct",))            # incomplete pair: not listed
+    assert C.list_stems(tmp_path) == ["0001", "0002"]
+    raw = torch.load(tmp_path / "0001_drct_part.pt", weights_only=True)
+    assert sorted(raw) == ["features", "filename", "hr", "lr", "outputs"] and list(raw["outputs"]) == ["drct"]
+    assert tuple(raw["outputs"]["drct"].shape) == (1, 3, 4 * h, 4 * w) and tuple(raw["lr"].shape) == (3, h, w)
+    raw = torch.load(tmp_path / "0001_rest_part.pt", weights_only=True)
+    assert sorted(raw["outputs"]) == ["grl", "nafnet"] and tuple(raw["features"]["nafnet"].shape) == (1, 64, h, w)
+    raw = torch.load(tmp_path / "0001_mamba_part.pt", weights_only=True)
+    assert raw["outputs"]["mamba"].dtype == torch.float16 and raw["features"]["mamba"].dtype == torch.float16
+    e = C.load_entry(tmp_path, "0001")
+    assert torch.equal(e["lr"], lr) and torch.equal(e["hr"], hr) and e["filename"] == "0001"
+    for k in ("drct", "grl", "nafnet"):
+        assert torch.equal(e["expert_imgs"][k], outs[k][0]) and torch.equal(e["expert_feats"][k], feats[k][0])
+    assert torch.equal(e["expert_imgs"]["mamba"], outs["mamba"][0].half().float())
+    assert torch.equal(e["expert_feats"]["mamba"], feats["mamba"][0].half().float())
+    e2 = C.load_entry(tmp_path, "0002")
+    assert tuple(e2["expert_imgs"]["mamba"].shape) == (3, 4 * h, 4 * w) and not e2["expert_imgs"]["mamba"].any()
+    assert tuple(e2["expert_feats"]["mamba"].shape) == (180, h, w) and not e2["expert_feats"]["mamba"].any()
+    assert "expert_feats" not in C.load_entry(tmp_path, "0002", load_features=False)
+    b = C.collate([e, e2])
+    assert tuple(b["lr"].shape) == (2, 3, h, w) and tuple(b["expert_feats"]["nafnet"].shape) == (2, 64, h, w)
+    assert b["filename"] == ["0001", "0002"]
+
+
 def test_strided_shard_matches_reference_scheme():
     S = mod("shard")
     items = list(range(10))

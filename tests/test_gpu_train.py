@@ -72,3 +72,34 @@ def test_train_entry_points_reject_bad_arguments():
     with pytest.raises(hip.FfsrError, match="invalid argument"):
         hip.call("ffsr_l1_clamp_loss_f32", x.data_ptr(), 2, x.data_ptr(), 3, None, 0, x.data_ptr(), 1024, x.data_ptr(), 8, 3,
                  1.0, st)                                                                            # row stride < C
+
+
+def test_cache_extract_writes_what_the_oracle_experts_produce(tmp_path):
+    """the cache producer: four experts on the HIP engine -> the reference's 3-part files -> CachedSRDataset's view,
+    against the oracle's expert outputs / hooked features (expert half of io._process_image; 40x56 needs pad16 + crops)"""
+    from ffsr_oracle import pipeline
+    from ffsr_oracle.scan_c import selective_scan_c
+    from test_gpu_models import lr_image
+    W, E, C = mod("weights"), mod("engine"), mod("cache")
+    weights = W.random_weights(seed=40, small=True)
+    eng = E.Engine(weights, DEV)
+    lr = lr_image(31, 1, 40, 56)
+    hr = torch.rand(3, 160, 224, generator=torch.Generator().manual_seed(3))
+    outs, feats = C.extract(eng, lr)
+    imgs_o, feats_o, _ = pipeline.run_experts(weights, lr, naf_cfg=dict(enc_blks=(1, 1, 1, 1), mid_blks=1, dec_blks=(1, 1, 1, 1)),
+                                              scan_fn=selective_scan_c)
+    for k in ("drct", "grl", "nafnet", "mamba"):
+        assert tuple(outs[k].shape) == (1, 3, 160, 224) and tuple(feats[k].shape) == tuple(feats_o[k].shape)
+        assert (outs[k] - imgs_o[k]).abs().max().item() < 1e-3 and (feats[k] - feats_o[k]).abs().max().item() < 1e-3, k
+    C.save_entry(tmp_path, "0801x4", lr[0], hr, outs, feats)
+    e = C.load_entry(tmp_path, C.list_stems(tmp_path)[0])
+    assert torch.equal(e["expert_imgs"]["grl"], outs["grl"][0]) and torch.equal(e["expert_feats"]["nafnet"], feats["nafnet"][0])
+    assert (e["expert_imgs"]["mamba"] - imgs_o["mamba"][0]).abs().max().item() < 2e-3          # fp16 storage of the reference
+    # the loaded entry drives the fusion net exactly like the live path
+    lrm = E.nchw_to_map(lr, DEV)
+    imgs_m = {k: E.nchw_to_map(e["expert_imgs"][k][None], DEV) for k in ("drct", "grl", "nafnet")}
+    imgs_m["mamba"] = E.nchw_to_map(outs["mamba"], DEV)
+    feats_m = {k: E.nchw_to_map(feats[k], DEV) for k in feats}
+    live = E.map_to_nchw(eng.process(lrm))
+    cached = E.map_to_nchw(eng.fusion(lrm, imgs_m, feats_m))
+    assert (live - cached).abs().max().item() < 1e-6
