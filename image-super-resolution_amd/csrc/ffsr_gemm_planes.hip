@@ -16,8 +16,14 @@
 // GEMMs already run at 57-84 % of what the chip's plain streaming kernels reach on the same bytes (~4 TB/s): what is
 // left for them is fewer bytes (fusion), not a different pipeline.  (c) One workgroup walking all column tiles of its
 // 128-row panel (the A panel then stays in that CU's L1 / L2): 6-15 % slower -- each tile switch drains the epilogue's
-// stores through the shared vmcnt, and the grid loses parallelism.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN: that path (measured
-// ~16 B/clk/CU), not the matrix pipe, is what bounds the 128-row tile on long-K shapes.
+// stores through the shared vmcnt, and the grid loses parallelism.  The bytes each CU pulls through the L2 -> LDS path per MFMA scale with 1/BM + 1/BN; on the
+// long-K conv shapes this kernel moves ~15 B/clk/CU through that path at ~36-45 % MFMA utilisation.  That is NOT the
+// hardware's fill limit: tools/probe/ldsdma_rate.hip (4 KiB per wave and round, wait + barrier per round) sustains 24 / 47 /
+// 70 B/clk/CU from an L2-resident source with 4 / 8 / 16 waves per CU, i.e. the rate grows with the bytes in flight.  With
+// two stages the loads of step t+1 have exactly one step of MFMA work (~0.5 us) to land, less than the loaded L2 latency:
+// the step time is latency-, not throughput-bound.  Three stages cost the second resident workgroup at BN >= 128 (measured:
+// no gain); the open direction is more, thinner stages (BK = 16) at two workgroups per CU.  Fewer staged bytes per step do
+// help today (the tap-strip kernel below).
 // LDS image of one stage: A_hi | A_lo | B_hi | B_lo, rows of 64 B (32 bf16), no padding: one LDS-DMA instruction
 // writes 16 rows x 64 B lane-linear.  Bank conflicts are removed on the SOURCE side: the 16-byte chunk c of row r is
 // stored in slot c ^ ((r >> 2) & 3) of its row (each lane fetches the chunk that belongs in its slot), and the
@@ -424,9 +430,8 @@ int launch_planes(PlaneArgs& a, hipStream_t st) {
 }
 
 // ---- 3x3 (stride 1, pad 1) convolutions: the three horizontal taps share their A rows.
-// The tile kernel above fetches a fresh 128-row A tile per tap: the LDS fill (LDS-DMA instructions through the texture path,
-// ~16 B/clk/CU), not the matrix pipe, bounds the thin-N 3x3 convs (N = 45 / 60 / 128: 24..32 KB staged per K step against
-// 0.5..1 us of MFMA).  Output rows are consecutive pixels, so the A rows of tap (ky, kx) are the rows of tap (ky, 0) moved
+// The tile kernel above fetches a fresh 128-row A tile per tap: the time to land a step's staged bytes (24..32 KB per K step
+// against 0.5..1 us of MFMA at N = 45 / 60 / 128), not the matrix pipe, bounds the thin-N 3x3 convs.  Output rows are consecutive pixels, so the A rows of tap (ky, kx) are the rows of tap (ky, 0) moved
 // down by kx: one 130-row strip (144 staged) per (ky, 32-channel chunk) serves kx = 0, 1, 2 through fragment reads at row
 // offsets 0 / 1 / 2 -- 9 pieces per plane instead of 24.  What a shifted read picks up across an image border (the
 // neighbouring pixel of the previous / next image row) is zeroed in the fragment registers from the per-row tap mask.
