@@ -21,9 +21,12 @@
 // hardware's fill limit: tools/probe/ldsdma_rate.hip (4 KiB per wave and round, wait + barrier per round) sustains 24 / 47 /
 // 70 B/clk/CU from an L2-resident source with 4 / 8 / 16 waves per CU, i.e. the rate grows with the bytes in flight.  With
 // two stages the loads of step t+1 have exactly one step of MFMA work (~0.5 us) to land, less than the loaded L2 latency:
-// the step time is latency-, not throughput-bound.  Three stages cost the second resident workgroup at BN >= 128 (measured:
-// no gain); the open direction is more, thinner stages (BK = 16) at two workgroups per CU.  Fewer staged bytes per step do
-// help today (the tap-strip kernel below).
+// the step time is latency-, not throughput-bound.  Three 32-deep stages of the 64-column tile (72 KB, still 2 WGs/CU) are
+// 13 % faster than two on the Cin 180 -> 45 / 60 convs; at BN >= 128 the third stage costs the second resident workgroup
+// (measured: slower).  (d) Thinner stages instead -- 16-deep K steps (32-byte LDS rows), 3 / 4 / 5 of them in flight in the
+// same 80 KB, correct, burst issue: 13-40 % SLOWER on every shape (token GEMMs, 3x3 convs, the HR refine conv) and slower the
+// more stages: halving the MFMA burst between barriers costs more than the longer prefetch distance returns.  Fewer staged
+// bytes per step do help (the tap-strip kernel below).
 // LDS image of one stage: A_hi | A_lo | B_hi | B_lo, rows of 64 B (32 bf16), no padding: one LDS-DMA instruction
 // writes 16 rows x 64 B lane-linear.  Bank conflicts are removed on the SOURCE side: the 16-byte chunk c of row r is
 // stored in slot c ^ ((r >> 2) & 3) of its row (each lane fetches the chunk that belongs in its slot), and the

@@ -11,7 +11,7 @@ for H, W, Cin, N, _ in SHAPES:
     xp = ops.split_planes(x)
     line = f"{H}x{W} Cin {Cin:4d} N {N:4d}:"
     base = None
-    for bn, stages in ((0, 0), (64, 2), (64, 4), (128, 2), (128, 4)):
+    for bn, stages in ((0, 0), (64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4)):
         if bn == 64 and N > 128:
             continue
         out = ops.conv2d(xp, cv, bm=128 if bn else 0, bn=bn, stages=stages)
