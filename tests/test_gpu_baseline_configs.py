@@ -98,3 +98,36 @@ def test_image_too_small_for_reflect_pad_raises():
         torch.nn.functional.pad(torch.zeros(1, 3, 8, 40), (0, 8, 0, 8), mode="reflect")
     with pytest.raises(hip.FfsrError):
         eng.process(E.nchw_to_map(lr_image(24, 1, 8, 40), DEV))
+
+
+def test_large_image_680x1020_and_the_size_guard():
+    """four times BASELINE's pixels (680x1020 LR -> 2720x4080: NAFNet level-0 maps of 1.4 G elements, 2.8 GB plane
+    operands): 64-bit addressing end to end.  The same size-independent check as at 340x510 -- the default arithmetic
+    agrees with the exact mode to 1e-3 -- on reduced-depth experts of the real width (every kernel of the path runs).
+    Beyond 2^32 bytes per plane operand the C ABI refuses (32-bit byte offsets) instead of wrapping."""
+    W, E, ops, hip = mod("weights"), mod("engine"), mod("ops"), mod("hip")
+    weights = W.random_weights(seed=91, small=True)
+    lr = lr_image(25, 1, 680, 1020)
+    outs = {}
+    for mode in ("bf16x3", "f32"):
+        ops.set_gemm_mode(mode)
+        try:
+            eng = E.Engine(weights, DEV)
+            outs[mode] = eng.process(E.nchw_to_map(lr, DEV))[..., :3].float().cpu()
+            del eng
+            torch.cuda.empty_cache()
+        finally:
+            ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
+    a, b = outs["bf16x3"], outs["f32"]
+    assert a.shape == (1, 2720, 4080, 3) and torch.isfinite(a).all() and a.min().item() >= 0.0 and a.max().item() <= 1.0
+    diff = err(a, b)
+    print(f"680x1020: max |fast - exact| = {diff:.3e}")
+    assert diff < TOL, diff
+    # a plane operand of 2^32 bytes or more is rejected before any launch (M = 2^24 rows x 128 channels x 2 B)
+    z = ops.zero_page(DEV)
+    cv = ops.pack_conv(torch.zeros(8, 128, 1, 1), None, DEV)
+    tiny = torch.zeros(64, device=DEV)
+    with pytest.raises(hip.FfsrError, match="invalid argument"):
+        hip.call("ffsr_conv2d_planes", tiny.data_ptr(), tiny.data_ptr(), 128, cv.phi.data_ptr(), cv.plo.data_ptr(),
+                 cv.phi.shape[0], z.data_ptr(), None, tiny.data_ptr(), None, None, None, None, None, 0, 1, 4096, 4096, 8, 8, 0,
+                 1, 1, 1, 0, 0, 0, 0.0, 1.0, 1.0, 128, 64, 2, torch.cuda.current_stream().cuda_stream)
