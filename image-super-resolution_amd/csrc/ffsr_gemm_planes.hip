@@ -635,7 +635,9 @@ int launch_strip3(const PlaneArgs& a, hipStream_t st) {
 }
 // Measured (tools/strip_bench.py): with the 64-column tile (6 MFMAs per K half) the burst of 4 pieces behind the barrier is
 // faster than one piece per MFMA triple (N 45: 132 vs 147 us, N 60: 156 vs 161, 64 -> 64 at HR/2: 187 vs 201); with the
-// 128-column tile the interleaved issue is marginally ahead (212 vs 216 us, 2274 vs 2284 us).
+// 128-column tile the interleaved issue is marginally ahead (212 vs 216 us, 2274 vs 2284 us).  A third weight buffer
+// (weights fetched two steps ahead behind a counted vmcnt, 60 KB = 2 WGs/CU instead of 3): bit-identical, no change
+// (157 vs 156 us, 144.5 vs 142.8 us) -- not kept.
 template <int BN, bool GELU>
 int launch_strip2(const PlaneArgs& a, hipStream_t st) {
   return launch_strip3<BN, GELU, (BN >= 128 ? 1 : 0)>(a, st);
