@@ -169,7 +169,7 @@ class Conv:
 
 
 def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=None, cin_pad=None,
-              in_perm=None, gate_pairs=False) -> Conv:
+              gate_pairs=False) -> Conv:
     """w: [N, Cin, KH, KW] (nn.Conv2d) or [N, K] (nn.Linear).  cin_pad: padded channel count of the input map.
     Load-time weight preparation (layout change, zero padding, bf16 hi/lo split): done with torch ops on `device`."""
     w = w.detach().float().to(device)
