@@ -12,15 +12,26 @@
     if (!(cond)) return FFSR_EINVAL; \
   } while (0)
 
-static inline int ffsr_launch_status() { return hipGetLastError() == hipSuccess ? FFSR_OK : FFSR_ELAUNCH; }
-
-// Every kernel launch of the library goes through FFSR_LAUNCH: it first clears the thread's sticky "last error" (the
-// host framework's own event / stream queries leave hipErrorNotReady there), so that ffsr_launch_status() reports the
-// outcome of OUR launch and not a stale code of an unrelated runtime call.
-#define FFSR_LAUNCH(...)              \
-  do {                                \
-    (void)hipGetLastError();          \
-    hipLaunchKernelGGL(__VA_ARGS__);  \
+// Launch bookkeeping.  Every kernel launch of the library goes through FFSR_LAUNCH: it first clears the thread's sticky
+// "last error" (the host framework's own event / stream queries leave hipErrorNotReady there), launches, and records a
+// failure of THIS launch in a thread-local flag.  ffsr_launch_status() at the end of an entry point reports (and resets)
+// that flag, so a multi-launch entry point (FFT band split, selective scan, ...) fails if ANY of its launches failed, not
+// only the last one.
+inline int& ffsr_launch_failed() {
+  static thread_local int failed = 0;
+  return failed;
+}
+static inline int ffsr_launch_status() {
+  int& f = ffsr_launch_failed();
+  const int rc = f ? FFSR_ELAUNCH : FFSR_OK;
+  f = 0;
+  return rc;
+}
+#define FFSR_LAUNCH(...)                                         \
+  do {                                                           \
+    (void)hipGetLastError();                                     \
+    hipLaunchKernelGGL(__VA_ARGS__);                             \
+    if (hipGetLastError() != hipSuccess) ffsr_launch_failed() = 1; \
   } while (0)
 
 // activation codes shared by the GEMM/conv epilogue, the depthwise conv and the elementwise kernels

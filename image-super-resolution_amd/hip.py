@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libffsr_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ffsr.h")
 
-_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong}
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong, "double": ctypes.c_double}
 _lib = None
 
 

@@ -61,3 +61,50 @@ def ssim(img1, img2, crop_border=0, test_y_channel=True) -> float:
                      ops.ld(mu1), out.data_ptr(), ops.ld(out), ops.rows(x), torch.cuda.current_stream().cuda_stream)
         vals.append(float(ops.colmean(out).double().mean().item()))
     return sum(vals) / len(vals)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The evaluation script's variant (utils/utils_image.py:148-189, what eval.py reports): uint8 in, OpenCV's 8-bit Y,
+# float64 PSNR, scikit-image's SSIM -- integer kernels of csrc/ffsr_metrics.hip.
+def psnr_ssim_u8(output_img, target_img, crop_border=4, test_y_channel=True, device="cuda"):
+    """cal_psnr_ssim on two uint8 HxWx3 RGB images (numpy arrays or tensors) -> (psnr dB, ssim), both Python floats.
+    Mirrors :154-187: common size, border crop, Y = cv2.COLOR_RGB2YCrCb luma (or the three RGB planes), mse -> PSNR,
+    structural_similarity(data_range=255)."""
+    from .engine import require_gpu
+    device = require_gpu(device)
+    imgs = []
+    for im in (output_img, target_img):
+        t = torch.as_tensor(im)
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError(f"expected uint8 HxWx3 images, got {t.dtype} {tuple(t.shape)}")
+        imgs.append(t)
+    h, w = min(imgs[0].shape[0], imgs[1].shape[0]), min(imgs[0].shape[1], imgs[1].shape[1])
+    c = int(crop_border)
+    Hc, Wc = h - 2 * c, w - 2 * c
+    P = 1 if test_y_channel else 3
+    planes = []
+    with torch.cuda.device(device):
+        st = torch.cuda.current_stream(device).cuda_stream
+        for t in imgs:
+            t = t[:h, :w].contiguous().to(device)
+            pl = torch.empty(P, Hc, Wc, dtype=torch.uint8, device=device)
+            ops.hip.call("ffsr_u8_planes", t.data_ptr(), h, w, c, int(test_y_channel), pl.data_ptr(), st)
+            planes.append(pl)
+        n_partial = 1024
+        partial = torch.empty(2 * n_partial, dtype=torch.float64, device=device)
+        out = torch.empty(2, dtype=torch.float64, device=device)
+        ops.hip.call("ffsr_psnr_ssim_u8", planes[0].data_ptr(), planes[1].data_ptr(), P, Hc, Wc, partial.data_ptr(),
+                     n_partial, out.data_ptr(), st)
+        mse, ssim_v = out.tolist()
+    return (float("inf") if mse == 0 else 20.0 * math.log10(255.0 / math.sqrt(mse))), ssim_v
+
+
+def cal_psnr_ssim(output_image_path, target_image_path, crop_border=4, test_y_channel=True):
+    """utils/utils_image.py:148 with its own signature: two image files -> (psnr, ssim)."""
+    import numpy as np
+    from PIL import Image
+
+    def read(p):
+        with Image.open(p) as im:
+            return np.array(im.convert("RGB"), dtype=np.uint8)
+    return psnr_ssim_u8(read(output_image_path), read(target_image_path), crop_border, test_y_channel)

@@ -224,6 +224,18 @@ int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, co
 int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12, int ld,
                       float* out, int ldo, long long M, void* stream);
 
+/* uint8 PSNR / SSIM of the evaluation script, utils/utils_image.py:148-189 (cal_psnr_ssim).
+ * ffsr_u8_planes: img [H, W, 3] uint8 RGB -> planes [P, H - 2 crop, W - 2 crop] uint8 of the border-cropped window
+ * (:162-164): P = 1, the luma of cv2.cvtColor(COLOR_RGB2YCrCb) for 8-bit images (OpenCV's fixed point
+ * (4899 R + 9617 G + 1868 B + 2^13) >> 14, :168-169) when y_channel, else P = 3 planes R, G, B (:171-172).
+ * ffsr_psnr_ssim_u8: out[0] = mean squared error over the P planes (exact integer sum; PSNR = 20 log10(255 / sqrt(mse)),
+ * :175-179), out[1] = skimage.metrics.structural_similarity(data_range=255[, channel_axis=2]) (:183-187): 7x7 uniform
+ * window, sample covariance, mean of the map over the pixels whose window lies inside the plane, mean over planes.
+ * out / partial are device doubles (partial: 2 * n_partial of scratch). */
+int ffsr_u8_planes(const unsigned char* img, int H, int W, int crop, int y_channel, unsigned char* planes, void* stream);
+int ffsr_psnr_ssim_u8(const unsigned char* pa, const unsigned char* pb, int P, int Hc, int Wc, double* partial,
+                      int n_partial, double* out, void* stream);
+
 /* ---- optimiser side of the cached-feature training step (the backward kernels of the fusion phases are
  * not built yet).  Flat fp32 buffers, deterministic two-stage reductions; `partial` is caller-owned scratch of at least
  * 1024 floats (n_partial says how many).

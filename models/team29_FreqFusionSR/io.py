@@ -42,8 +42,30 @@ def _imread_uint(path):
 
 def _imsave(img, path):
     from PIL import Image
-    kw = {"compress_level": 1} if path.lower().endswith(".png") else {}     # cv2.imwrite's default PNG level
+    low = path.lower()
+    if low.endswith(".png"):
+        kw = {"compress_level": 1}                 # cv2.imwrite's default PNG level
+    elif low.endswith((".jpg", ".jpeg")):
+        kw = {"quality": 95}                       # cv2.imwrite's default IMWRITE_JPEG_QUALITY (io.py:119)
+    else:
+        kw = {}
     Image.fromarray(img).save(path, **kw)
+
+
+def _rank_device(device):
+    """The device this process computes on.  ``None`` -> cuda (io.py:306-307).  Under a one-process-per-GPU launch
+    (WORLD_SIZE > 1, torchrun) an index-less ``cuda`` -- what test.py:78-81 passes -- resolves to ``cuda:LOCAL_RANK``,
+    the reference's per-process GPU choice (scripts/kaggle_inference_fixed.py:126-127), and becomes the process's
+    current device BEFORE the process group, the weight broadcast or any kernel touches a GPU."""
+    shard, engine = _pkg("shard"), _pkg("engine")
+    device = torch.device("cuda") if device is None else torch.device(device)
+    rank, world = shard.rank_world()
+    if world > 1 and device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)))
+    device = engine.require_gpu(device)
+    if device.index is not None:
+        torch.cuda.set_device(device)
+    return device
 
 
 def _load_engine(model_dir, device):
@@ -59,6 +81,12 @@ def _load_engine(model_dir, device):
             if fusion_cfg.get(k, v) != v:
                 raise ValueError(f"configs/train_config.yaml model.fusion.{k}={fusion_cfg[k]} is not the submitted "
                                  f"architecture ({v}) this engine implements")
+        # the reference builds a different network when an improvement is switched off (io.py:186-193 ->
+        # CompleteEnhancedFusionSR(enable_*=...)); this engine implements the submitted one: all six enabled
+        for k, v in (fusion_cfg.get("improvements") or {}).items():
+            if v is not True:
+                raise ValueError(f"configs/train_config.yaml model.fusion.improvements.{k}={v!r}: this engine implements "
+                                 "the submitted architecture with every improvement enabled")
     weights, shard, engine = _pkg("weights"), _pkg("shard"), _pkg("engine")
     rank, world = shard.init_process_group()
     templates = weights.random_weights(shapes_only=True)      # keys + shapes; values come from the files (rank 0)
@@ -68,10 +96,7 @@ def _load_engine(model_dir, device):
 
 
 def main(model_dir, input_path, output_path, device=None):
-    engine_mod = _pkg("engine")
-    if device is None:
-        device = torch.device("cuda")
-    device = engine_mod.require_gpu(device)
+    device = _rank_device(device)
     print(f"\n{'=' * 60}\n  FreqFusionSR (MI355X HIP engine)\n{'=' * 60}")
     print(f"  Weights : {model_dir}\n  Input   : {input_path}\n  Output  : {output_path}\n  Device  : {device}\n")
     eng, rank, world = _load_engine(model_dir, device)

@@ -236,5 +236,56 @@ def main():
         print(f"  {f}: {os.path.getsize(os.path.join(GOLDEN, f)) / 1e6:.2f} MB")
 
 
+def _load_reference_file(rel, name):
+    """one reference source file imported from where it lies (no package __init__ executed)"""
+    import importlib.util
+    from ref_harness import REFERENCE_ROOT
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REFERENCE_ROOT, rel))
+    mod = importlib.util.module_from_spec(spec)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(mod)
+    return mod
+
+
+def metric_pairs():
+    """two seeded image pairs [1,3,H,W]: smooth image + noise (values also leave [0,1]: the metrics clamp)"""
+    pairs = []
+    for seed, (h, w), noise in ((21, (48, 64), 0.02), (22, (37, 53), 0.08)):
+        g = torch.Generator().manual_seed(seed)
+        a = lr_input(seed, 1, h, w)
+        b = a + noise * torch.randn(a.shape, generator=g)
+        pairs.append((a * 1.1 - 0.05, b))
+    return pairs
+
+
+@torch.no_grad()
+def golden_metrics():
+    """SURVEY 8 f4: calculate_psnr / calculate_ssim_torch / calculate_ssim of src/utils/metrics.py (torch + numpy only;
+    scikit-image is absent here, so calculate_ssim takes its torch branch) on two seeded pairs -> tests/golden/metrics.pt (inputs + expected values)"""
+    from ffsr_oracle import metrics as om
+    ref = _load_reference_file("src/utils/metrics.py", "ref_src_utils_metrics")
+    out = []
+    for i, (a, b) in enumerate(metric_pairs()):
+        for crop in (0, 4):
+            for y in (False, True):
+                p = ref.calculate_psnr(a, b, crop_border=crop, test_y_channel=y)
+                s = ref.calculate_ssim(a, b, crop_border=crop, test_y_channel=y)
+                po, so = om.psnr(a, b, crop, y), om.ssim(a, b, crop, y)
+                print(f"  pair {i} crop {crop} y {int(y)}: psnr {p:.6f} (oracle {po:.6f})  ssim {s:.8f} (oracle {so:.8f})")
+                assert abs(p - po) < 1e-4 and abs(s - so) < 1e-6
+                out.append({"pair": i, "crop_border": crop, "test_y_channel": y, "psnr": p, "ssim": s})
+    torch.save({"pairs": [(a.clone(), b.clone()) for a, b in metric_pairs()], "cases": out},
+               os.path.join(GOLDEN, "metrics.pt"))
+
+
 if __name__ == "__main__":
-    main()
+    what = sys.argv[1:] or ["inference", "metrics", "train"]
+    if "inference" in what:
+        main()
+    if "metrics" in what:
+        golden_metrics()
+    if "train" in what:
+        golden_train()

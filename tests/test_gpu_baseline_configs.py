@@ -102,7 +102,7 @@ def test_image_too_small_for_reflect_pad_raises():
 
 def test_large_image_680x1020_and_the_size_guard():
     """four times BASELINE's pixels (680x1020 LR -> 2720x4080: NAFNet level-0 maps of 1.4 G elements, 2.8 GB plane
-    operands): 64-bit addressing end to end.  The same size-independent check as at 340x510 -- the default arithmetic
+    operands): 64-bit addressing end to end.  The size-independent check (the oracle cannot run this size in minutes) -- the default arithmetic
     agrees with the exact mode to 1e-3 -- on reduced-depth experts of the real width (every kernel of the path runs).
     Beyond 2^32 bytes per plane operand the C ABI refuses (32-bit byte offsets) instead of wrapping."""
     W, E, ops, hip = mod("weights"), mod("engine"), mod("ops"), mod("hip")

@@ -1,0 +1,95 @@
+"""io.main under a one-process-per-GPU launch (WORLD_SIZE = 2, gloo on CPU, engine stubbed): every rank must select
+cuda:LOCAL_RANK before anything touches a GPU (the reference's per-process device, scripts/kaggle_inference_fixed.py:
+126-127) and write exactly sorted(files)[rank::2] under the input names (io.py:323-345)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import importlib, json, os, sys
+    import numpy as np, torch
+    sys.path.insert(0, %(root)r)
+    E = importlib.import_module("image-super-resolution_amd.engine")
+    S = importlib.import_module("image-super-resolution_amd.shard")
+    W = importlib.import_module("image-super-resolution_amd.weights")
+    log = {"set_device": [], "engine_device": None, "bcast_device": None, "order": []}
+
+    # ---- stubs for everything that needs a GPU; the process group, the broadcast and the sharding stay real (gloo)
+    E.require_gpu = lambda d: torch.device(d)
+    torch.cuda.set_device = lambda d: (log["set_device"].append(str(d)), log["order"].append("set_device"))
+    torch.cuda.synchronize = lambda *a, **k: None
+    real_init = S.init_process_group
+    S.init_process_group = lambda backend=None: (log["order"].append("init_pg"), real_init("gloo"))[1]
+    real_bcast = S.broadcast_weights
+    def bcast(w, device, src=0):
+        log["bcast_device"] = str(device)
+        return real_bcast(w, "cpu", src)
+    S.broadcast_weights = bcast
+    small = lambda **kw: {"fusion": {"a": torch.zeros(3, device="meta" if kw.get("shapes_only") else "cpu")}}
+    W.random_weights = small
+    W.load_model_dir = lambda model_dir, templates, fill: {"fusion": {"a": torch.tensor([1., 2., 3.])}}
+
+    class Engine:
+        def __init__(self, weights, device, scale=4):
+            log["engine_device"] = str(device)
+            assert torch.equal(weights["fusion"]["a"].cpu(), torch.tensor([1., 2., 3.]))     # rank 0's values reached us
+        def process_u8(self, img):
+            return np.repeat(np.repeat(img, 4, 0), 4, 1)
+    E.Engine = Engine
+
+    from models.team29_FreqFusionSR import main
+    main(model_dir="unused", input_path=sys.argv[1], output_path=sys.argv[2], device=torch.device("cuda"))
+    print("LOG " + json.dumps(log))
+""")
+
+
+def test_main_two_ranks_pick_their_gpu_and_their_images(tmp_path):
+    from PIL import Image
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    names = [f"{i:04d}x4.png" for i in (3, 1, 7, 5)] + ["0009x4.jpg"]
+    rng = np.random.RandomState(0)
+    for n in names:
+        Image.fromarray(rng.randint(0, 256, (6, 8, 3)).astype(np.uint8)).save(inp / n)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(inp), str(out)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    import json
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        log = json.loads([ln for ln in o.splitlines() if ln.startswith("LOG ")][0][4:])
+        assert log["set_device"] == [f"cuda:{r}"], log
+        assert log["engine_device"] == f"cuda:{r}" and log["bcast_device"] == f"cuda:{r}", log
+        assert log["order"].index("set_device") < log["order"].index("init_pg"), log       # device first, then RCCL
+        assert f"Processing {len(sorted(names)[r::2])} of 5 images on rank {r}/2" in o
+    assert sorted(os.listdir(out)) == sorted(names)                     # union of the two shards, input names kept
+    for n in names:
+        with Image.open(out / n) as im:
+            assert im.size == (32, 24)
+
+
+def test_rank_device_single_process_keeps_the_callers_device(monkeypatch):
+    import importlib
+    import torch
+    sys.path.insert(0, ROOT)
+    io = importlib.import_module("models.team29_FreqFusionSR.io")
+    E = importlib.import_module("image-super-resolution_amd.engine")
+    monkeypatch.setattr(E, "require_gpu", lambda d: torch.device(d))
+    seen = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: seen.append(str(d)))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert io._rank_device(None) == torch.device("cuda") and seen == []
+    assert io._rank_device(torch.device("cuda:3")) == torch.device("cuda:3") and seen == ["cuda:3"]
+    monkeypatch.setenv("WORLD_SIZE", "8"), monkeypatch.setenv("RANK", "5"), monkeypatch.setenv("LOCAL_RANK", "5")
+    assert io._rank_device(torch.device("cuda")) == torch.device("cuda:5")
+    assert io._rank_device(torch.device("cuda:2")) == torch.device("cuda:2")        # an explicit index wins

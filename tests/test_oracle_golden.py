@@ -101,3 +101,32 @@ def test_c_scan_matches_torch_scan():
     a = selective_scan_c(u, dt, A, Bm, Cm, D, delta_bias=bias, delta_softplus=True)
     b = selective_scan_ref(u, dt, A, Bm, Cm, D, delta_bias=bias, delta_softplus=True)
     assert (a - b).abs().max() < 1e-4
+
+
+def test_metrics_oracle_matches_reference_values():
+    """tests/golden/metrics.pt holds calculate_psnr / calculate_ssim of the imported reference
+    (src/utils/metrics.py:76-186) on two seeded pairs, crop 0 / 4, RGB / BT.601-Y."""
+    from ffsr_oracle import metrics as om
+    g = load_golden("metrics.pt")
+    assert len(g["cases"]) == 8
+    for c in g["cases"]:
+        a, b = g["pairs"][c["pair"]]
+        assert abs(om.psnr(a, b, c["crop_border"], c["test_y_channel"]) - c["psnr"]) < 1e-4, c
+        assert abs(om.ssim(a, b, c["crop_border"], c["test_y_channel"]) - c["ssim"]) < 1e-6, c
+
+
+def test_u8_metrics_oracle_known_answers():
+    """the evaluation script's uint8 variant (utils/utils_image.py:148-189; parity unpinned: cv2 / skimage are absent):
+    OpenCV's fixed-point luma on values with known results, PSNR of a constant offset, SSIM of identical images"""
+    import numpy as np
+    from ffsr_oracle import metrics as om
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128]]], dtype=np.uint8)
+    assert om.rgb2y_opencv_u8(px)[0].tolist() == [255, 0, 76, 150, 29, 128]     # 0.299 / 0.587 / 0.114, rounded
+    rng = np.random.RandomState(0)
+    a = rng.randint(0, 250, (40, 52, 3)).astype(np.uint8)
+    p, s = om.psnr_ssim_u8(a, a.copy())
+    assert p == float("inf") and abs(s - 1.0) < 1e-12
+    p, s = om.psnr_ssim_u8(a, a + 5, crop_border=0, test_y_channel=False)          # mse = 25 exactly
+    assert abs(p - 20 * np.log10(255.0 / 5.0)) < 1e-12 and 0.9 < s < 1.0
+    p4, _ = om.psnr_ssim_u8(a, a + 5, crop_border=4, test_y_channel=True)          # Y of a uniform +5 shift is +5 (+-1 rounding)
+    assert abs(p4 - 20 * np.log10(255.0 / 5.0)) < 0.5
