@@ -157,9 +157,9 @@ __global__ void dft_cols_mask_kernel(const float2* __restrict__ Zr, const float2
   }
   re *= norm;
   im *= norm;
-  const float m = mask[ky * Wf + k];
+  const float m = mask ? mask[ky * Wf + k] : 1.f;
   Zlo[idx] = make_float2(re * m, im * m);
-  Zhi[idx] = make_float2(re * (1.f - m), im * (1.f - m));
+  if (Zhi) Zhi[idx] = make_float2(re * (1.f - m), im * (1.f - m));
 }
 // K3: inverse columns  U[s,b,c,y,k] = sum_ky Z[s,b,c,ky,k] e^{+2 pi i ky y / H}
 __global__ void idft_cols_kernel(const float2* __restrict__ Z, const float2* __restrict__ twH, float2* __restrict__ U, int SBC,
@@ -250,5 +250,20 @@ extern "C" int ffsr_fft_bands_f32(const float* img, int ldi, const float* twW, c
   FFSR_LAUNCH(idft_cols_kernel, dim3(grid_for(2 * n)), dim3(256), 0, ST, Zs, (const float2*)twH, U, 2 * B * 3, H, Wf);
   FFSR_LAUNCH(idft_rows_kernel, dim3(grid_for((long long)2 * B * 3 * H * W)), dim3(256), 0, ST, U, (const float2*)twW,
                      scale, bands, ldb, B, H, W, Wf, norm);
+  return ffsr_launch_status();
+}
+
+// torch.fft.rfft2(img, norm="ortho") of a 3-channel map: spec [B*3, H, W/2+1] complex (interleaved re, im).  Used by the
+// backward pass of the FFT band split (the adjoint of irfft2 is a weighted rfft2: see ffsr_fft_mask_grad_f32).
+// work: float2 scratch of B*3*H*(W/2+1) elements.
+extern "C" int ffsr_rfft2_ortho_f32(const float* img, int ldi, const float* twW, const float* twH, float* work, float* spec,
+                                    int B, int H, int W, void* stream) {
+  FFSR_CHECK(img && twW && twH && work && spec && B > 0 && H > 1 && W > 1 && ldi >= 3);
+  const int Wf = W / 2 + 1;
+  const size_t n = (size_t)B * 3 * H * Wf;
+  const float norm = 1.0f / sqrtf((float)H * (float)W);
+  FFSR_LAUNCH(dft_rows_kernel, dim3(grid_for(n)), dim3(256), 0, ST, img, ldi, (const float2*)twW, (float2*)work, B, H, W, Wf);
+  FFSR_LAUNCH(dft_cols_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST, (const float2*)work, (const float2*)twH,
+              (const float*)nullptr, (float2*)spec, (float2*)nullptr, B * 3, H, Wf, norm);
   return ffsr_launch_status();
 }

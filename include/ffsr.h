@@ -255,6 +255,110 @@ int ffsr_adamw_ema_f32(float* param, const float* grad, float* exp_avg, float* e
                        const float* grad_sumsq, float max_norm, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int step, float ema_decay, void* stream);
 
+/* ================= backward pass of the fusion network (what loss.backward() runs for
+ * CompleteEnhancedFusionSR.forward_with_precomputed in train.py:323-336).  Each entry point replaces the autograd node(s)
+ * of the cited forward call.  Parameter gradients are ACCUMULATED (dst += value); all reductions are deterministic
+ * two-stage sums over caller-owned scratch. */
+
+/* p[0..n) = 0 (hipMemsetAsync): the zero_grad() of train.py:355 and zero-padded channel buffers. */
+int ffsr_zero_f32(float* p, long long n, void* stream);
+
+/* nn.Conv2d weight [N, Cin, KH, KW] -> the packed operand of ffsr_conv2d_f32 (dst_f32 [rows, KH*KW*Cp]) and / or of
+ * ffsr_conv2d_bf16x3 (bf16 hi / lo planes [rows_pad, ldw], zero padded).  transpose = 0: the forward operator (rows = N,
+ * Cp >= Cin channels per tap); transpose = 1: the input-gradient operator of the stride-1 "same" convolution (rows = Cin,
+ * Cp >= N channels per tap, taps flipped) -- autograd's conv2d backward-data as a forward convolution of dY.
+ * The weights change every optimiser step, so this runs per step instead of once at load. */
+int ffsr_pack_conv_f32(const float* w, int N, int Cin, int KH, int KW, int transpose, float* dst_f32, int Cp, void* dst_hi,
+                       void* dst_lo, int rows_pad, int ldw, void* stream);
+/* depthwise weight [C, 1, KH, KW] -> tap-major [KH*KW, C] (ffsr_dwconv2d_f32's layout); flip = 1: input-gradient operator. */
+int ffsr_pack_dwconv_f32(const float* w, int C, int KH, int KW, int flip, float* dst, void* stream);
+
+/* Weight gradient of a stride-1 convolution / linear layer on the f32 MFMA:
+ * dw [N, Cin, KH, KW] += sum_pix dy[pix, n] * x[pix + (ky - pad_h, kx - pad_w), c].  partial: scratch of partial_floats
+ * floats (>= KH*KW*N*Cin; more = more pixel splits in flight).  Replaces autograd's conv2d / linear backward-weight for
+ * every nn.Conv2d / nn.Linear of the fusion net (e.g. enhanced_fusion_v2.py:569-576, large_kernel_attention.py:134-138). */
+int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial,
+                        long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
+                        void* stream);
+/* Depthwise (groups = C) weight gradient, KH*KW <= 25: large_kernel_attention.py:58-76 (5x5, 1x21, 21x1).
+ * partial: nchunk * KH*KW * C floats. */
+int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial, int nchunk, int B, int H,
+                          int W, int C, int KH, int KW, int pad_h, int pad_w, void* stream);
+
+/* dx = (accumulate ? dx : 0) + alpha * dy * act'(ref); ref = the activation's input (from_output 0) or its output
+ * (from_output 1; ReLU / LeakyReLU / sigmoid only).  act codes as in the forward library, plus 6 = clamp(., 0, 1)
+ * (edge_enhancement.py:260; gradient passes on the closed interval like torch.clamp). */
+int ffsr_act_bwd_f32(const float* dy, int ldy, const float* ref, int ldr, float* dx, int ldx, long long M, int C, int act,
+                     float slope, int from_output, float alpha, int accumulate, void* stream);
+/* out = alpha * sa[0] * a + beta * sb[0] * b  (sa / sb: learnable DEVICE scalars or NULL = 1; b optional): the residual
+ * scalings scale1 / scale2 (large_kernel_attention.py:143-148), residual_weight_*, ResBlock.scale, edge_strength,
+ * residual_scale, the band scales of multi_domain_frequency.py:192-194,297,385 -- read on the device, no host sync. */
+int ffsr_axpby_dev_f32(const float* a, int lda, const float* sa, float alpha, const float* b, int ldb, const float* sb,
+                       float beta, float* out, int ldo, long long M, int C, void* stream);
+/* out[0] (+)= scale * sum_{m, c} a * (b ? b : 1): gradient of a learnable scalar.  partial: n_partial doubles. */
+int ffsr_dot_acc_f32(const float* a, int lda, const float* b, int ldb, long long M, int C, double* partial, int n_partial,
+                     float* out, float scale, int accumulate, void* stream);
+/* out[c * ostride] (+)= scale * sum_m a[m, c] * (b ? b[m, c] : 1): bias gradients and per-channel scale gradients.
+ * partial: nchunk * C floats. */
+int ffsr_coldot_acc_f32(const float* a, int lda, const float* b, int ldb, long long M, int C, float* partial, int nchunk,
+                        float* out, int ostride, float scale, int accumulate, void* stream);
+/* out[m * ldo] (+)= alpha * sum_c a[m, c] * b[m, c]: gradient of a per-pixel gate that was broadcast over the channels
+ * (hierarchical_fusion.py:42, edge_enhancement.py:88). */
+int ffsr_rowdot_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo, long long M, int C, float alpha,
+                    int accumulate, void* stream);
+
+/* nn.BatchNorm2d in TRAIN mode (large_kernel_attention.py:84,128,131 under model.train()): batch statistics over the M rows,
+ * stat [2, C] <- (mean, rstd), scale_shift [2, C] <- the fused affine y = x * scale + shift (apply with ffsr_unary_f32),
+ * running_mean / running_var updated in place (momentum, unbiased variance; NULL = skip).
+ * partial: nchunk * C floats, sums: 2 * C floats of scratch. */
+int ffsr_bn_train_stats_f32(const float* x, int ldx, long long M, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, float* partial, int nchunk, float* sums, float* stat, float* scale_shift,
+                            float* run_mean, float* run_var, void* stream);
+/* its backward: dx (may alias dy), dgamma / dbeta += .  coef: 3 * C floats of scratch. */
+int ffsr_bn_train_bwd_f32(const float* x, int ldx, const float* dy, int ldy, float* dx, int lddx, long long M, int C,
+                          const float* gamma, const float* stat, float* partial, int nchunk, float* sums, float* coef,
+                          float* dgamma, float* dbeta, void* stream);
+/* nn.LayerNorm backward (C <= 256; large_kernel_attention.py:190,288-289): dx, dgamma / dbeta +=.
+ * partial: 2 * nblock * C floats. */
+int ffsr_layernorm_bwd_f32(const float* x, int ldx, const float* gamma, float eps, const float* dy, int ldy, float* dx, int lddx,
+                           float* partial, int nblock, float* dgamma, float* dbeta, long long M, int C, void* stream);
+
+/* Adjoints of ffsr_bilinear_f32 / ffsr_avgpool2_f32 (gather form): din (+)= mul * A^T dout. */
+int ffsr_bilinear_bwd_f32(const float* dout, int ldo, float* din, int ldi, int B, int Hi, int Wi, int Ho, int Wo, int C, float mul,
+                          int accumulate, void* stream);
+int ffsr_avgpool2_bwd_f32(const float* dout, int ldo, float* din, int ldi, int B, int H, int W, int C, int accumulate,
+                          void* stream);
+
+/* Backward of ffsr_pixel_mha_f32 (attention dropout 0): dqkv [S*T, 3E].
+ * scratch: 2 * S * heads * T * T floats. */
+int ffsr_pixel_mha_bwd_f32(const float* qkv, int ldq, const float* dout, int ldo, float* dqkv, int lddq, float* scratch,
+                           long long S, int T, int E, int heads, void* stream);
+
+/* softmax over the C <= 8 channels of every row and its backward (F.softmax(freq_logits, dim=1), enhanced_fusion_v2.py:743). */
+int ffsr_softmax_c_f32(const float* x, int ldx, float* y, int ldy, long long M, int C, void* stream);
+int ffsr_softmax_c_bwd_f32(const float* y, int ldy, const float* dy, int lddy, float* dx, int ldx, long long M, int C,
+                           void* stream);
+/* out[c] = sum_e x[3 e + c] * g[e] / (normalize ? sum_e g[e] + 1e-8 : 1), 4 experts x 3 channels: the frequency-guided
+ * sum (enhanced_fusion_v2.py:744-747) and the gated mean of the dynamic selection (:761-768); backward: dx (+)=, dg =. */
+int ffsr_expert_sum_f32(const float* x, int ldx, const float* g, int ldg, float* out, int ldo, long long M, int normalize,
+                        void* stream);
+int ffsr_expert_sum_bwd_f32(const float* x, int ldx, const float* g, int ldg, const float* dy, int lddy, float* dx, int lddx,
+                            float* dg, int lddg, long long M, int normalize, int accumulate_dx, void* stream);
+/* Backward of ffsr_selector_gates_f32: draw [M, 4], ddiff [M, 1], dtemperature[0] +=.  partial: n_partial doubles. */
+int ffsr_selector_gates_bwd_f32(const float* raw, int ldr, const float* diff, int ldd, const float* temperature,
+                                const float* dgates, int ldg, float* draw, int lddr, float* ddiff, int lddd, double* partial,
+                                int n_partial, float* dtemperature, long long M, void* stream);
+
+/* FFT band split, backward w.r.t. the learnable mask (multi_domain_frequency.py:366-383):
+ * ffsr_rfft2_ortho_f32: spec [B*3, H, W/2+1] complex = torch.fft.rfft2(img, norm="ortho") (work: as many float2).
+ * ffsr_fft_mask_grad_f32: dmask [H, W/2+1] = w_k * sum_{b,c} Re(X conj(Ghat)) with X = xlo + xhi (the masked spectra the
+ * forward ffsr_fft_bands_f32 left in its work buffer at float offsets 2 n and 4 n, n = B*3*H*(W/2+1)) and
+ * Ghat = rfft2_ortho(dL/dlow - dL/dhigh). */
+int ffsr_rfft2_ortho_f32(const float* img, int ldi, const float* twW, const float* twH, float* work, float* spec, int B, int H,
+                         int W, void* stream);
+int ffsr_fft_mask_grad_f32(const float* xlo, const float* xhi, const float* ghat, float* dmask, int B, int H, int W,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

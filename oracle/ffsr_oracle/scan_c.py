@@ -15,10 +15,34 @@ LIB = os.path.join(os.path.dirname(_HERE), "_build", "libscan_ref.so")
 _lib = None
 
 
+def _cpu_tag():
+    """identifies the instruction set the library was compiled for (-march=native): the flags line of /proc/cpuinfo"""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(flags.encode()).hexdigest()
+
+
 def build(force=False):
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+    """gcc -O3 -march=native -fopenmp (+ libmvec's vector expf).  The .so travels with the repo snapshot to the GPU box,
+    whose host CPU may differ from the build container's: a tag file records the CPU flags the library was built for and
+    a mismatch triggers a rebuild there."""
+    tag_path, tag = LIB + ".tag", _cpu_tag()
+    stale = not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC)
+    if not stale:
+        try:
+            stale = open(tag_path).read().strip() != tag
+        except OSError:
+            stale = True
+    if force or stale:
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", SRC, "-o", LIB, "-lm"])
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fno-math-errno", "-shared", "-fPIC", SRC, "-o", LIB,
+                               "-lmvec", "-lm"])
+        with open(tag_path, "w") as f:
+            f.write(tag)
     return LIB
 
 

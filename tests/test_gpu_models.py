@@ -163,7 +163,7 @@ def test_full_depth_experts_and_fusion_vs_oracle_64x64(mode):
     assert final < TOL, (mode, final)
 
 
-def test_full_size_340x510_vs_oracle():
+def test_full_size_340x510_vs_oracle(capsys):
     """BASELINE's headline geometry, checked DIRECTLY against the CPU oracle: one 340x510 LR image -> 1360x2040,
     full-depth experts, default arithmetic.  The oracle (oracle/ffsr_oracle/pipeline.py with the C scan) needs about two
     minutes of the box's host cores for this image.  Compared: every expert's PRE-clamp SR and hooked feature on the padded
@@ -198,12 +198,20 @@ def test_full_size_340x510_vs_oracle():
     torch.cuda.empty_cache()
 
     t0 = time.time()
+
+    def progress(msg):          # the oracle pass is minutes of CPU work: say so past pytest's capture
+        with capsys.disabled():
+            print(f"  [340x510 oracle] {msg} ({time.time() - t0:.0f} s)", flush=True)
+
     with torch.no_grad():
         lp, (h, w) = pipeline.pad16(lr)
         assert torch.equal(E.map_to_nchw(lpm), lp)
-        want_raw = {"drct": odrct.drct_forward(weights["drct"], lp), "grl": ogrl.grl_forward(weights["grl"], lp),
-                    "nafnet": onaf.nafnet_sr(weights["nafnet"], lp, 4),
-                    "mamba": omamba.mambair_forward(weights["mamba"], lp, scan_fn=selective_scan_c)}
+        want_raw = {}
+        for n, fn in (("drct", lambda: odrct.drct_forward(weights["drct"], lp)), ("grl", lambda: ogrl.grl_forward(weights["grl"], lp)),
+                      ("nafnet", lambda: onaf.nafnet_sr(weights["nafnet"], lp, 4)),
+                      ("mamba", lambda: omamba.mambair_forward(weights["mamba"], lp, scan_fn=selective_scan_c))):
+            want_raw[n] = fn()
+            progress(f"{n} done")
         report = {}
         for n, (sr_o, feat_o) in want_raw.items():
             report[n] = tuple(err(a, b) / max(1.0, b.abs().max().item()) for a, b in zip(raw[n], (sr_o, feat_o)))
@@ -215,7 +223,7 @@ def test_full_size_340x510_vs_oracle():
         feats_o["nafnet"] = torch.nn.functional.interpolate(want_raw["nafnet"][1], size=(h, w), mode="bilinear",
                                                             align_corners=False)
         want = ofusion.fusion_forward(weights["fusion"], lp[:, :, :h, :w], imgs_o, feats_o, 4)
-    print(f"oracle: {time.time() - t0:.0f} s on {torch.get_num_threads()} host threads")
+    progress(f"fusion done, {torch.get_num_threads()} host threads")
     for n, (e_sr, e_feat) in report.items():
         assert e_sr < TOL and e_feat < TOL, (n, e_sr, e_feat)
     for n in imgs_o:
