@@ -69,6 +69,7 @@ __device__ __forceinline__ float act_grad(float r, int act, float slope, int fro
       return s * (1.0f + r * (1.0f - s));
     }
     case 6: return (r >= 0.f && r <= 1.f) ? 1.f : 0.f;   // clamp(v, 0, 1): torch passes the gradient on the closed interval
+    case 7: return r >= slope ? 1.f : 0.f;               // clamp(v, min=slope)
     default: return 1.f;
   }
 }
@@ -636,7 +637,7 @@ extern "C" int ffsr_pack_dwconv_f32(const float* w, int C, int KH, int KW, int f
 
 extern "C" int ffsr_act_bwd_f32(const float* dy, int ldy, const float* ref, int ldr, float* dx, int ldx, long long M, int C,
                                 int act, float slope, int from_output, float alpha, int accumulate, void* stream) {
-  FFSR_CHECK(dy && ref && dx && M > 0 && C > 0 && ldy >= C && ldr >= C && ldx >= C && act >= 0 && act <= 6);
+  FFSR_CHECK(dy && ref && dx && M > 0 && C > 0 && ldy >= C && ldr >= C && ldx >= C && act >= 0 && act <= 7);
   FFSR_CHECK(!from_output || act == FFSR_ACT_RELU || act == FFSR_ACT_LRELU || act == FFSR_ACT_SIGMOID || act == FFSR_ACT_NONE);
   FFSR_LAUNCH(act_bwd_kernel, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, ref, ldr, dx, ldx, M, C, act, slope,
               from_output, alpha, accumulate);

@@ -164,7 +164,7 @@ class FusionNet:
     def frequency_bands(self, lr):
         """lr [B,h,w,3] -> bands [B,h,w,36] = 9 bands x (3 channels + zero pad)."""
         B, h, w, _ = lr.shape
-        bands = torch.zeros(B, h, w, 36, device=lr.device)
+        bands = ops.zeros(B, h, w, 36, device=lr.device)
         ops.dct_bands(lr, self.dct_D, self.dct_masks, self.dct_scale, bands)
         sub = ops.dwt_db4(lr, self.dwt_lo, self.dwt_hi)
         for i in range(4):
@@ -264,7 +264,7 @@ class FusionNet:
                 self._edge_refine(0, lap, out=feats[..., :32])
             else:
                 ops.bilinear(self._edge_refine(lv, lap), Hh, Wh, out=feats[..., 32 * lv:32 * lv + 32])
-        cat6 = torch.zeros(B, Hh, Wh, 8, device=self.device)
+        cat6 = ops.zeros(B, Hh, Wh, 8, device=self.device)
         ops.unary(sr, out=cat6[..., :3])
         edge = ops.conv2d(ops.conv2d(feats, self.ef0, act=ACT_GELU), self.ef2, out=cat6[..., 3:6])
         gate = ops.conv2d(ops.conv2d(cat6, self.eg0, act=ACT_GELU), self.eg2, act=ACT_SIGMOID)

@@ -1,0 +1,412 @@
+"""CompleteEnhancedFusionSR in TRAIN mode on the HIP kernels: forward_with_precomputed + its backward pass.
+
+What ``model.train(); sr = model.forward_with_precomputed(lr, expert_imgs, expert_feats); loss.backward()`` does in the
+reference's cached-feature training loop (train.py:297-336), restated over the tape of autograd.py.  Differences between
+train and eval mode that the reference has and this file reproduces:
+
+* the six nn.BatchNorm2d of the two LKA blocks use BATCH statistics and update their running statistics -- per CALL: the
+  shared cross-band block runs once per band (9 updates per step), lka_global once per expert (4)
+  (large_kernel_attention.py:84,128,131,247-251,404);
+* no clamp after the collaborative modulation (large_kernel_attention.py:420-423) and none on the final image
+  (enhanced_fusion_v2.py:792-795); the clamp inside the Laplacian refinement stays (edge_enhancement.py:260);
+* nn.MultiheadAttention's attention dropout (p = 0.1, :196,298) is DISABLED here, as SURVEY 8(d) allows for config 5: the
+  reference's dropout mask comes from torch's Philox stream, which a from-scratch engine cannot reproduce bit-for-bit.
+
+Same GPU-first layout as fusion.py (token tensors instead of stack / permute copies, concatenations as channel slices, the
+1x1 128->32 modulation conv applied before the bilinear upsample).  Nothing is folded into the weights here: every
+parameter keeps its own gradient.  All 9 bands go through the LKA block for the BatchNorm statistics, but only bands 0-2
+reach the loss (routing_lr = e0 + e1 + e2, enhanced_fusion_v2.py:713), so only those are taped.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from . import hip, ops
+from .autograd import ACT_CLAMP01, ACT_CLAMP_MIN, BnP, ConvP, DwP, Param, Tape, Var, ch, tok
+from .fusion import EXPERTS
+from .ops import ACT_GELU, ACT_RELU, ACT_SIGMOID, _ptr, _stream
+
+BUFFER_KEYS = ("running_mean", "running_var", "num_batches_tracked", "dct_basis", "dct_basis_t", "low_mask", "mid_mask",
+               "high_mask", "lo_row", "hi_row", "lo_col", "hi_col", "gaussian.kernel")
+
+
+def is_parameter(key: str) -> bool:
+    """nn.Parameter vs registered buffer of CompleteEnhancedFusionSR, by state_dict key"""
+    return not key.endswith(BUFFER_KEYS)
+
+
+class _LKA:
+    def __init__(self, P, buf, p, device):
+        C = P[p + "norm1.weight"].v.shape[0]
+        self.s1, self.s2 = P[p + "scale1"], P[p + "scale2"]
+        bn = lambda q: BnP(P[q + ".weight"], P[q + ".bias"], buf[q + ".running_mean"], buf[q + ".running_var"])
+        self.n1, self.n2, self.lbn = bn(p + "norm1"), bn(p + "norm2"), bn(p + "lka.bn")
+        self.dw5 = DwP(P[p + "lka.local_conv.weight"], device, (2, 2))
+        self.dwh = DwP(P[p + "lka.h_conv.weight"], device, (0, 10))
+        self.dwv = DwP(P[p + "lka.v_conv.weight"], device, (10, 0))
+        self.pw = ConvP(P[p + "lka.pw_conv.weight"], None, device)
+        self.f0 = ConvP(P[p + "ffn.0.weight"], P[p + "ffn.0.bias"], device)
+        self.f2 = ConvP(P[p + "ffn.2.weight"], P[p + "ffn.2.bias"], device)
+        self.convs, self.dws = [self.pw, self.f0, self.f2], [self.dw5, self.dwh, self.dwv]
+
+    def __call__(self, t: Tape, x: Var, stats_only=False):
+        """LKABlock.forward (large_kernel_attention.py:143-149) in train mode.  stats_only: stop after norm2's statistics
+        (the band's output is not used; only the running statistics matter)."""
+        n = t.bn(x, self.n1)
+        a = t.dwconv(t.dwconv(t.dwconv(n, self.dw5), self.dwh), self.dwv)
+        a = t.act(t.bn(t.conv(a, self.pw), self.lbn), ACT_SIGMOID)
+        x1 = t.add_scaled(x, t.mul(n, a), self.s1.v, self.s1.g)
+        n2 = t.bn(x1, self.n2)
+        if stats_only:
+            return None
+        f = t.conv(t.conv(n2, self.f0, act=ACT_GELU), self.f2)
+        return t.add_scaled(x1, f, self.s2.v, self.s2.g)
+
+
+class _MHA:
+    def __init__(self, P, p, device, heads):
+        self.heads = heads
+        self.inp = ConvP(P[p + "in_proj_weight"], P[p + "in_proj_bias"], device)
+        self.out = ConvP(P[p + "out_proj.weight"], P[p + "out_proj.bias"], device)
+        self.E = self.out.N
+        self.convs = [self.inp, self.out]
+
+    def __call__(self, t: Tape, normed: Var, S, T):
+        qkv = t.linear(normed, self.inp)
+        return t.linear(t.pixel_mha(qkv, S, T, self.E, self.heads), self.out)
+
+
+class FusionTrainNet:
+    """params: name -> Param (views into the optimiser's flat parameter / gradient buffers); buffers: name -> device tensor
+    (BatchNorm running statistics are updated in place, the rest are constants)."""
+
+    def __init__(self, params: Dict[str, Param], buffers: Dict[str, torch.Tensor], device, scale=4):
+        self.device, self.scale = torch.device(device), scale
+        P, buf = params, buffers
+        self.P = P
+        cp = lambda k, **kw: ConvP(P[k + ".weight"], P.get(k + ".bias"), device, **kw)
+        f = lambda k: buf[k].float().contiguous()
+        # ---- phase 2 constants
+        self.dct_D = f("freq_decomp.dct.dct_basis")
+        self.dct_masks = torch.stack([f("freq_decomp.dct.low_mask"), f("freq_decomp.dct.mid_mask"),
+                                      f("freq_decomp.dct.high_mask")]).reshape(3, 64).contiguous()
+        self.dwt_lo = f("freq_decomp.dwt.lo_row")[0].reshape(-1).contiguous()
+        self.dwt_hi = f("freq_decomp.dwt.hi_row")[0].reshape(-1).contiguous()
+        self.ones = torch.ones(4, device=device)
+        self._tw = {}
+        # ---- phase 3
+        p = "cross_band."
+        self.band_proj = cp(p + "band_proj", cin_pad=4)
+        self.cb_mha = _MHA(P, p + "band_attention.", device, 4)
+        self.cb_lka = _LKA(P, buf, p + "lka_block.", device)
+        self.cb_out = cp(p + "out_proj")
+        # ---- phase 4
+        p = "collaborative."
+        self.align = {n: cp(f"{p}align_layers.{n}") for n in EXPERTS}
+        self.co_mha = _MHA(P, p + "cross_attn.", device, 8)
+        self.co_f0, self.co_f2 = cp(p + "ffn.0"), cp(p + "ffn.2")
+        self.co_lka = _LKA(P, buf, p + "lka_global.", device)
+        self.mod0 = [cp(f"{p}modulation.{i}.0") for i in range(4)]
+        self.mod2 = [cp(f"{p}modulation.{i}.2") for i in range(4)]
+        # ---- phase 5
+        p = "multi_res."
+        self.stage = [dict(c0=cp(f"{p}stage{s}_conv.0"), c2=cp(f"{p}stage{s}_conv.2"), g0=cp(f"{p}stage{s}_gate.gate.0"),
+                           g2=cp(f"{p}stage{s}_gate.gate.2"), r0=cp(f"{p}stage{s}_res.block.0"),
+                           r2=cp(f"{p}stage{s}_res.block.2"), rs=P[f"{p}stage{s}_res.scale"]) for s in (1, 2, 3)]
+        self.rgb0, self.rgb2 = cp(p + "to_rgb.0"), cp(p + "to_rgb.2")
+        self.fw0, self.fw2 = cp("freq_weight_conv.0", cin_pad=4), cp("freq_weight_conv.2")
+        # ---- phase 6
+        p = "dynamic_selector."
+        self.dn = [cp(p + "difficulty_net.0", cin_pad=4), cp(p + "difficulty_net.2"), cp(p + "difficulty_net.4")]
+        self.gn = [cp(p + "gate_net.0", cin_pad=4), cp(p + "gate_net.2"), cp(p + "gate_net.4")]
+        # ---- phase 7 / 7b
+        self.refine = [cp(f"refine.{i}", cin_pad=4 if i == 0 else None) for i in range(0, 12, 2)]
+        p = "edge_enhance."
+        gk = torch.zeros(4, 1, 5, 5, device=device)
+        gk[:3] = f(p + "gaussian.kernel")
+        self.gauss = DwP(gk, device, (2, 2))
+        self.refiners = [dict(c1=cp(f"{p}edge_refiners.{i}.conv1", cin_pad=4), c2=cp(f"{p}edge_refiners.{i}.conv2"),
+                              c3=cp(f"{p}edge_refiners.{i}.conv3"), pj=cp(f"{p}edge_refiners.{i}.proj", cin_pad=4),
+                              a0=cp(f"{p}edge_refiners.{i}.attn.attn.0"), a2=cp(f"{p}edge_refiners.{i}.attn.attn.2"))
+                         for i in range(3)]
+        self.ef0, self.ef2 = cp(p + "fusion.0"), cp(p + "fusion.2")
+        self.eg0, self.eg2 = cp(p + "edge_gate.0", cin_pad=8), cp(p + "edge_gate.2")
+        # every packed operand that must follow the weights
+        convs, dws = [], []
+        for obj in list(self.__dict__.values()):
+            self._collect(obj, convs, dws)
+        self._convs, self._dws = convs, dws
+        self.repack()
+
+    def _collect(self, obj, convs, dws):
+        if isinstance(obj, ConvP):
+            convs.append(obj)
+        elif isinstance(obj, DwP):
+            if obj.param is not None:
+                dws.append(obj)
+        elif isinstance(obj, (_LKA, _MHA)):
+            convs.extend(obj.convs)
+            dws.extend(getattr(obj, "dws", []))
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                self._collect(v, convs, dws)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                self._collect(v, convs, dws)
+
+    def repack(self):
+        """after every optimiser step: the packed conv / depthwise operands follow the flat parameter buffer"""
+        for c in self._convs:
+            c.repack()
+        for d in self._dws:
+            d.repack()
+
+    def bn_modules(self):
+        return [self.cb_lka.n1, self.cb_lka.lbn, self.cb_lka.n2, self.co_lka.n1, self.co_lka.lbn, self.co_lka.n2]
+
+    # ------------------------------------------------------------------------------------------ phase 2
+    def _twiddles(self, h, w):
+        if (h, w) not in self._tw:
+            def tw(n):
+                j = torch.arange(n, dtype=torch.float64) * (2 * math.pi / n)
+                return torch.stack([torch.cos(j), torch.sin(j)], 1).float().contiguous().to(self.device)
+            self._tw[(h, w)] = (tw(w), tw(h))
+        return self._tw[(h, w)]
+
+    def _param_map(self, t: Tape, prm: Param, shape) -> Var:
+        """a parameter tensor used as a map: its Var, whose gradient is added into the flat gradient buffer at the end"""
+        v = Var(prm.v.reshape(shape))
+
+        def bw():
+            if v.g is not None:
+                gm = prm.g.reshape(shape)
+                ops.scale_add(gm, v.g, out=gm)
+        t._rec(bw)
+        return v
+
+    def frequency_bands(self, t: Tape, lr: torch.Tensor) -> Var:
+        """lr [B,h,w,3] -> Var bands [B,h,w,36] (9 bands x (3 channels + zero pad)); multi_domain_frequency.py:593."""
+        P = self.P
+        B, h, w, _ = lr.shape
+        wf = w // 2 + 1
+        raw = ops.zeros(B, h, w, 36, device=self.device)
+        ops.dct_bands(lr, self.dct_D, self.dct_masks, self.ones, raw)                     # unit scales: applied below
+        sub = ops.dwt_db4(lr, self.dwt_lo, self.dwt_hi)
+        for i in range(4):
+            ops.bilinear(sub[..., 4 * i:4 * i + 4], h, w, out=raw[..., 12 + 4 * i:16 + 4 * i])
+        # FFT mask = sigmoid(bilinear(freq_mask_logits) * clamp(temperature, min=1))   (:366-375)
+        logits = self._param_map(t, P["freq_decomp.fft.freq_mask_logits"], (1, 64, 64, 1))
+        lb = t.bilinear(logits, h, wf)
+        temp = P["freq_decomp.fft.temperature"]
+        tc = ops.unary(temp.v.reshape(1, 1, 1, 1), clamp=(1.0, 3.0e38))
+        tc_g = ops.zeros(4, device=self.device)
+
+        def temp_bw():           # through the clamp(min=1): passes where temperature >= 1
+            hip.call("ffsr_act_bwd_f32", _ptr(tc_g), 1, _ptr(temp.v), 1, _ptr(temp.g), 1, 1, 1, ACT_CLAMP_MIN, 1.0, 0, 1.0, 1, _stream())
+        t._rec(temp_bw)
+        mask = t.act(t.add_scaled(None, lb, tc, tc_g), ACT_SIGMOID, out=torch.empty(1, h, wf, 1, device=self.device))
+        twW, twH = self._twiddles(h, w)
+        n = B * 3 * h * wf
+        work = torch.empty(10 * n, device=self.device)
+        hip.call("ffsr_fft_bands_f32", _ptr(lr), ops.ld(lr), _ptr(twW), _ptr(twH), _ptr(mask.v), _ptr(self.ones), _ptr(work),
+                 _ptr(raw), 36, B, h, w, _stream())
+        raws = [Var(raw[..., 4 * i:4 * i + 3], req=(i >= 7)) for i in range(9)]
+
+        def fft_bw():            # d loss / d mask from the gradients of the two raw FFT bands
+            g_lo, g_hi = raws[7].g, raws[8].g
+            if g_lo is None or g_hi is None:
+                return
+            G = ops.scale_add(g_lo, g_hi, beta=-1.0)
+            spec, wk = torch.empty(2 * n, device=self.device), torch.empty(2 * n, device=self.device)
+            hip.call("ffsr_rfft2_ortho_f32", _ptr(G), ops.ld(G), _ptr(twW), _ptr(twH), _ptr(wk), _ptr(spec), B, h, w, _stream())
+            dmask = torch.empty(1, h, wf, 1, device=self.device)
+            hip.call("ffsr_fft_mask_grad_f32", work.data_ptr() + 4 * 2 * n, work.data_ptr() + 4 * 4 * n, _ptr(spec), _ptr(dmask),
+                     B, h, w, _stream())
+            t.acc(mask, dmask)
+        t._rec(fft_bw)
+        # learnable band scales (:192-194, :297, :385): bands_i = scale_i * raw_i
+        scales = [(P["freq_decomp.dct.band_scale"], i) for i in range(3)] + \
+                 [(P["freq_decomp.dwt.subband_scale"], i) for i in range(4)] + [(P["freq_decomp.fft.band_scale"], i) for i in range(2)]
+        bands = ops.zeros(B, h, w, 36, device=self.device)
+        parts = [t.add_scaled(None, raws[i], prm.v[j:j + 1], prm.g[j:j + 1], out=bands[..., 4 * i:4 * i + 3])
+                 for i, (prm, j) in enumerate(scales)]
+        return t.join(parts, bands, [ch(4 * i, 4 * i + 3) for i in range(9)]), parts
+
+    # ------------------------------------------------------------------------------------------ phase 3
+    def cross_band_routing(self, t: Tape, bands: Var, band_parts) -> Var:
+        P = self.P
+        B, h, w, _ = bands.v.shape
+        Pn = B * h * w
+        rows = Var(bands.v.reshape(Pn * 9, 4))
+
+        def rows_bw():
+            if rows.g is not None:           # [Pn*9, 3] with a zeroed 4th column -> the [B,h,w,36] layout of the bands
+                g = rows.g
+                t.acc(bands, g.as_strided((B, h, w, 36), (h * w * 36, w * 36, 36, 1), g.storage_offset()))
+        t._rec(rows_bw)
+        proj = t.linear(rows, self.band_proj)                                                      # [Pn*9, 64]
+        nrm = t.layernorm(proj, P["cross_band.norm.weight"], P["cross_band.norm.bias"])
+        attn = t.add(self.cb_mha(t, nrm, Pn, 9), proj)
+        feats = t.split(attn, [tok(i, 9, B, h, w) for i in range(9)])
+        routing = None
+        for i in range(9):           # the shared block sees the bands in order: 9 BatchNorm running-statistics updates
+            if i < 3:
+                e = t.add(t.conv(self.cb_lka(t, feats[i]), self.cb_out), band_parts[i])
+                routing = e if routing is None else t.add(routing, e)
+            else:
+                with t.no_grad():
+                    self.cb_lka(t, feats[i], stats_only=True)
+        return routing
+
+    # ------------------------------------------------------------------------------------------ phase 4
+    def collaborative(self, t: Tape, feats, imgs, enh: torch.Tensor) -> Var:
+        P = self.P
+        B, h, w, _ = feats["drct"].shape
+        _, Hh, Wh, _ = enh.shape
+        Pn = B * h * w
+        st = torch.empty(Pn * 4, 128, device=self.device)
+        sel = [tok(e, 4, B, h, w) for e in range(4)]
+        al = [t.conv(Var(feats[n], req=False), self.align[n], out=sel[e](st)) for e, n in enumerate(EXPERTS)]
+        stv = t.join(al, st, sel)
+        n1 = t.layernorm(stv, P["collaborative.norm1.weight"], P["collaborative.norm1.bias"])
+        s1 = t.add(stv, self.co_mha(t, n1, Pn, 4))
+        n2 = t.layernorm(s1, P["collaborative.norm2.weight"], P["collaborative.norm2.bias"])
+        s2 = t.add(s1, t.linear(t.linear(n2, self.co_f0, act=ACT_GELU), self.co_f2))
+        parts = t.split(s2, sel)
+        outs = []
+        for e, n in enumerate(EXPERTS):
+            t_lr = t.conv(self.co_lka(t, parts[e]), self.mod0[e])                  # 1x1 128->32 at LR (linear: commutes with the upsample)
+            g = t.act(t.bilinear(t_lr, Hh, Wh), ACT_GELU)
+            m = t.conv(g, self.mod2[e], act=ACT_SIGMOID)
+            u = t.affine(m, 0.2, 0.9)                                              # 1 + 0.2 (mod - 0.5)
+            outs.append(t.mul(Var(imgs[n], req=False), u, out=enh[..., 3 * e:3 * e + 3]))   # no clamp in train mode
+        return t.join(outs, enh, [ch(3 * e, 3 * e + 3) for e in range(4)])
+
+    # ------------------------------------------------------------------------------------------ phase 5
+    def _stage(self, t: Tape, i, x: Var) -> Var:
+        s = self.stage[i]
+        x = t.conv(t.conv(x, s["c0"], act=ACT_GELU), s["c2"], act=ACT_GELU)
+        gate = t.conv(t.conv(x, s["g0"], act=ACT_GELU), s["g2"], act=ACT_SIGMOID)
+        xg = t.mul(x, gate, row_broadcast=True)
+        r = t.conv(t.conv(xg, s["r0"], act=ACT_GELU), s["r2"])
+        return t.add_scaled(xg, r, s["rs"].v, s["rs"].g)
+
+    def hierarchical(self, t: Tape, cat3: torch.Tensor, enh: Var) -> Var:
+        P = self.P
+        B, Hh, Wh, _ = cat3.shape
+        s1, s2 = (max(Hh // 4, 1), max(Wh // 4, 1)), (max(Hh // 2, 1), max(Wh // 2, 1))
+        f1 = self._stage(t, 0, t.bilinear(enh, *s1))
+        cat2 = torch.empty(B, s2[0], s2[1], 76, device=self.device)
+        f1u = t.bilinear(f1, *s2, out=cat2[..., :64])
+        e2 = t.bilinear(enh, *s2, out=cat2[..., 64:76])
+        f2 = self._stage(t, 1, t.join([f1u, e2], cat2, [ch(0, 64), ch(64, 76)]))
+        rw12, rw23 = P["multi_res.residual_weight_1_2"], P["multi_res.residual_weight_2_3"]
+        f2 = t.add_scaled(f2, f1u, rw12.v, rw12.g)
+        f2u = t.bilinear(f2, Hh, Wh, out=cat3[..., :64])
+        f3 = self._stage(t, 2, t.join([f2u, enh], cat3, [ch(0, 64), ch(64, 76)]))
+        f2u32 = t.split(f2u, [ch(0, 32)])[0]
+        f3 = t.add_scaled(f3, f2u32, rw23.v, rw23.g)
+        return t.conv(t.conv(f3, self.rgb0, act=ACT_GELU), self.rgb2, act=ACT_SIGMOID)
+
+    # ------------------------------------------------------------------------------------------ phase 6
+    def selector(self, t: Tape, routing: Var):
+        d = t.conv(t.conv(t.conv(routing, self.dn[0], act=ACT_RELU), self.dn[1], act=ACT_RELU), self.dn[2], act=ACT_SIGMOID)
+        raw = t.conv(t.conv(t.conv(routing, self.gn[0], act=ACT_RELU), self.gn[1], act=ACT_RELU), self.gn[2])
+        return t.selector_gates(raw, d, self.P["dynamic_selector.temperature"]), d
+
+    # ------------------------------------------------------------------------------------------ phase 7b
+    def _edge_refine(self, t: Tape, lv, x: Var, lw: Var, out=None) -> Var:
+        r = self.refiners[lv]
+        o = t.conv(t.conv(x, r["c1"], act=ACT_GELU), r["c2"], act=ACT_GELU)
+        o = t.add(t.conv(o, r["c3"]), t.conv(x, r["pj"]))
+        att = t.conv(t.conv(o, r["a0"], act=ACT_GELU), r["a2"], act=ACT_SIGMOID)
+        f = t.mul(o, att, row_broadcast=True)
+        # f * softmax(level_weights)[lv]  (edge_enhancement.py:243-251): the weight is a device scalar inside lw.v
+        if lw.g is None:
+            lw.g, lw.gown = ops.zeros(1, 1, 1, 4, device=self.device)[..., :3], True
+        return t.add_scaled(None, f, lw.v[0, 0, 0, lv:lv + 1], lw.g[0, 0, 0, lv:lv + 1], out=out)
+
+    def laplacian_refine(self, t: Tape, sr: Var, lr: torch.Tensor) -> Var:
+        P = self.P
+        B, Hh, Wh, _ = sr.v.shape
+        pyr, cur = [], sr
+        for lv in range(3):
+            if lv < 2:
+                down = t.avgpool2(t.dwconv(self._widen4(t, cur), self.gauss))
+                up = t.bilinear(down, cur.v.shape[1], cur.v.shape[2])
+                pyr.append(t.add(cur, self._ch3(t, up), 1.0, -1.0))
+                cur = self._ch3(t, down)
+            else:
+                pyr.append(cur)
+        lwp = self._param_map(t, P["edge_enhance.level_weights"], (1, 1, 1, 3))
+        lw = t.softmax_c(lwp)
+        feats = torch.empty(B, Hh, Wh, 96, device=self.device)
+        parts = []
+        for lv, lap in enumerate(pyr):
+            if lv == 0:
+                parts.append(self._edge_refine(t, 0, lap, lw, out=feats[..., :32]))
+            else:
+                parts.append(t.bilinear(self._edge_refine(t, lv, lap, lw), Hh, Wh, out=feats[..., 32 * lv:32 * lv + 32]))
+        F = t.join(parts, feats, [ch(32 * lv, 32 * lv + 32) for lv in range(3)])
+        cat6 = ops.zeros(B, Hh, Wh, 8, device=self.device)
+        src = t.copy(sr, cat6[..., :3])
+        edge = t.conv(t.conv(F, self.ef0, act=ACT_GELU), self.ef2, out=cat6[..., 3:6])
+        c6 = t.join([src, edge], cat6[..., :6], [ch(0, 3), ch(3, 6)])
+        gate = t.conv(t.conv(c6, self.eg0, act=ACT_GELU), self.eg2, act=ACT_SIGMOID)
+        es = P["edge_enhance.edge_strength"]
+        pre = t.add_scaled(sr, t.mul(edge, gate, row_broadcast=True), es.v, es.g)
+        edged = t.act(pre, ACT_CLAMP01)
+        rs = P["residual_scale"]
+        bil = Var(ops.bilinear(lr, Hh, Wh), req=False)
+        return t.add_scaled(edged, bil, rs.v, rs.g)                                 # no final clamp in train mode
+
+    def _widen4(self, t: Tape, x: Var) -> Var:
+        """[.., 3] map with a zero 4th channel -> the same memory seen with 4 channels (for the 4-channel Gaussian)"""
+        y = Var(ops.widen(x.v, 4), x.req)
+
+        def bw():
+            if y.g is not None:
+                t.acc(x, y.g[..., :3], owned=True)
+        t._rec(bw)
+        return y
+
+    def _ch3(self, t: Tape, x: Var) -> Var:
+        """first three channels of a 4-channel map"""
+        y = Var(x.v[..., :3], x.req)
+
+        def bw():
+            if y.g is not None:
+                g = ops.zeros(*x.v.shape, device=self.device)
+                ops.unary(y.g, out=g[..., :3])
+                t.acc(x, g)
+        t._rec(bw)
+        return y
+
+    # ------------------------------------------------------------------------------------------ whole pipeline
+    def forward(self, t: Tape, lr, imgs, feats) -> Var:
+        """lr [B,h,w,3] map; imgs: 4 x [B,4h,4w,3]; feats: [B,h,w,180|180|64|180] -> Var SR [B,4h,4w,3] (unclamped)."""
+        B, h, w, _ = lr.shape
+        Hh, Wh = h * self.scale, w * self.scale
+        bands, band_parts = self.frequency_bands(t, lr)
+        routing = self.cross_band_routing(t, bands, band_parts)
+        cat3 = torch.empty(B, Hh, Wh, 76, device=self.device)
+        enh = self.collaborative(t, feats, imgs, cat3[..., 64:76])
+        hier = self.hierarchical(t, cat3, enh)
+        # 5b: frequency-guided weights from routing_lr (enhanced_fusion_v2.py:735-747)
+        r_hr = t.bilinear(routing, Hh, Wh)
+        wts = t.softmax_c(t.conv(t.conv(r_hr, self.fw0, act=ACT_GELU), self.fw2))
+        fused0 = t.add(hier, t.expert_sum(enh, wts, normalize=False), 0.7, 0.3)
+        # 6: dynamic expert selection (:757-774)
+        gates, diff = self.selector(t, routing)
+        dyn = t.expert_sum(enh, t.bilinear(gates, Hh, Wh), normalize=True)
+        bw_ = t.affine(t.bilinear(diff, Hh, Wh), 0.4, 0.3)
+        fused = t.add(fused0, t.mul(t.add(dyn, fused0, 1.0, -1.0), bw_, row_broadcast=True))
+        # 7: refine stack, fused + 0.1 * refine(fused) (:781)
+        r = fused
+        for cv in self.refine[:-1]:
+            r = t.conv(r, cv, act=ACT_GELU)
+        refined = t.add(fused, t.conv(r, self.refine[-1]), 1.0, 0.1)
+        return self.laplacian_refine(t, refined, lr)

@@ -70,13 +70,23 @@ def ld(t: torch.Tensor) -> int:
     return s
 
 
+def zeros(*shape, device) -> torch.Tensor:
+    """fp32 device buffer cleared through the C ABI (ffsr_zero_f32 = hipMemsetAsync on the current stream): torch only
+    allocates."""
+    buf = torch.empty(*shape, device=device, dtype=torch.float32)
+    if buf.numel():
+        hip.call("ffsr_zero_f32", buf.data_ptr(), buf.numel(), _stream())
+    return buf
+
+
 def new_map(B, H, W, C, device, zero_pad=True) -> torch.Tensor:
     """[B,H,W,C] view of a buffer whose pixel stride is padded to a multiple of 4 (pad channels zeroed)."""
     Cp = pad4(C)
     if Cp == C:
         return torch.empty(B, H, W, C, device=device, dtype=torch.float32)
-    buf = (torch.zeros if zero_pad else torch.empty)(B, H, W, Cp, device=device, dtype=torch.float32)
-    return buf[..., :C]
+    if zero_pad:
+        return zeros(B, H, W, Cp, device=device)[..., :C]
+    return torch.empty(B, H, W, Cp, device=device, dtype=torch.float32)[..., :C]
 
 
 def widen(t: torch.Tensor, C: int) -> torch.Tensor:
@@ -367,7 +377,7 @@ def _like(t: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     if t.dim() == 2:
         C = C or t.shape[1]
         Cp = pad4(C)
-        buf = torch.zeros(t.shape[0], Cp, device=t.device) if Cp != C else torch.empty(t.shape[0], C, device=t.device)
+        buf = zeros(t.shape[0], Cp, device=t.device) if Cp != C else torch.empty(t.shape[0], C, device=t.device)
         return buf[:, :C]
     return new_map(t.shape[0], t.shape[1], t.shape[2], C or t.shape[3], t.device)
 
@@ -614,7 +624,7 @@ def dct_bands(img, D, masks, scale, bands):
 def dwt_db4(img, lo, hi):
     B, H, W, _ = img.shape
     Hd, Wd = (H + 6) // 2 + 1, (W + 6) // 2 + 1
-    sub = torch.zeros(B, Hd, Wd, 16, device=img.device)
+    sub = zeros(B, Hd, Wd, 16, device=img.device)
     hip.call("ffsr_dwt_db4_f32", _ptr(img), ld(img), _ptr(lo), _ptr(hi), _ptr(sub), B, H, W, _stream())
     return sub
 

@@ -83,3 +83,63 @@ class FusionOptimizer:
                  _ptr(self.ema), self.n, _ptr(self._sumsq) if clip else None, float(self.max_norm or 0.0),
                  float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                  float(self.weight_decay), self.step_count, float(self.ema_decay or 0.0), _stream())
+
+
+class FusionTrainer:
+    """One cached-feature training step of the reference (train.py:297-359, ``train_epoch_cached``) on the HIP kernels:
+
+        sr = model.forward_with_precomputed(lr, expert_imgs, expert_feats)     # model.train(): fusion_train.FusionTrainNet
+        loss = L1Loss()(sr.clamp(0, 1), hr) / accumulation_steps               # ffsr_l1_clamp_loss_f32
+        loss.backward()                                                        # autograd.Tape.backward()
+        clip_grad_norm_ / optimizer.step() / zero_grad / ema.update            # FusionOptimizer.step (every accumulation_steps)
+
+    ``state_dict``: the fusion network's (parameters AND buffers; reference keys).  Attention dropout is off (see
+    fusion_train.py).  No CPU fallback."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, scale=4, accumulation_steps=1, **opt_kwargs):
+        from . import autograd, fusion_train
+        self.device = torch.device(device)
+        self.accumulation_steps = accumulation_steps
+        sd = {k: v for k, v in state_dict.items() if v.is_floating_point() and v.numel() > 0}
+        params = {k: v for k, v in sd.items() if fusion_train.is_parameter(k)}
+        with torch.cuda.device(self.device):
+            self.opt = FusionOptimizer(params, self.device, **opt_kwargs)
+            self.buffers = {k: v.detach().to(self.device, torch.float32).contiguous().clone() for k, v in sd.items()
+                            if not fusion_train.is_parameter(k)}
+            pv, gv = self.opt.views(), self.opt.views(self.opt.grad)
+            self.params = {k: autograd.Param(k, pv[k], gv[k]) for k in pv}
+            self.net = fusion_train.FusionTrainNet(self.params, self.buffers, self.device, scale)
+            self.tape = autograd.Tape(self.device)
+        self.micro = 0
+
+    def zero_grad(self):
+        hip.call("ffsr_zero_f32", _ptr(self.opt.grad), self.opt.n, _stream())
+
+    def forward_backward(self, lr, hr, imgs, feats):
+        """lr [B,h,w,3], hr [B,4h,4w,3], imgs / feats: dicts of channels-last maps on the device (cached expert outputs).
+        Accumulates d loss / d parameters into the flat gradient buffer; returns (loss [1] device tensor, sr map)."""
+        with torch.cuda.device(self.device), torch.no_grad():
+            sr = self.net.forward(self.tape, lr, imgs, feats)
+            loss, g = l1_clamp_loss(sr.v, hr, self.accumulation_steps)
+            sr.g, sr.gown = g, True
+            self.tape.backward()
+        return loss, sr.v
+
+    def step(self, lr, hr, imgs, feats, lr_rate: float = None):
+        """one micro-batch; the optimiser steps every `accumulation_steps` calls (train.py:344-359)"""
+        if self.micro == 0:
+            self.zero_grad()
+        loss, sr = self.forward_backward(lr, hr, imgs, feats)
+        self.micro += 1
+        if self.micro == self.accumulation_steps:
+            with torch.cuda.device(self.device):
+                self.opt.step(lr_rate)
+                self.net.repack()
+            self.micro = 0
+        return loss
+
+    def state_dict(self, ema=False) -> Dict[str, torch.Tensor]:
+        """reference-keyed state (parameters from the live weights or the EMA shadow, buffers incl. running statistics)"""
+        out = {k: v.clone() for k, v in self.opt.views(self.opt.ema if ema else None).items()}
+        out.update({k: v.clone() for k, v in self.buffers.items()})
+        return out

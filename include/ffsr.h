@@ -287,7 +287,8 @@ int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, flo
 
 /* dx = (accumulate ? dx : 0) + alpha * dy * act'(ref); ref = the activation's input (from_output 0) or its output
  * (from_output 1; ReLU / LeakyReLU / sigmoid only).  act codes as in the forward library, plus 6 = clamp(., 0, 1)
- * (edge_enhancement.py:260; gradient passes on the closed interval like torch.clamp). */
+ * (edge_enhancement.py:260; gradient passes on the closed interval like torch.clamp) and 7 = clamp(., min=slope)
+ * (multi_domain_frequency.py:374). */
 int ffsr_act_bwd_f32(const float* dy, int ldy, const float* ref, int ldr, float* dx, int ldx, long long M, int C, int act,
                      float slope, int from_output, float alpha, int accumulate, void* stream);
 /* out = alpha * sa[0] * a + beta * sb[0] * b  (sa / sb: learnable DEVICE scalars or NULL = 1; b optional): the residual

@@ -21,9 +21,11 @@ def conv(sd, p, x, pad=0, **kw):
     return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), padding=pad, **kw)
 
 
-def bn_eval(sd, p, x, eps=1e-5):
+def bn_eval(sd, p, x, eps=1e-5, train=False):
+    """nn.BatchNorm2d: running statistics in eval mode; in train mode batch statistics, and the running statistics in
+    ``sd`` are updated in place (momentum 0.1, unbiased variance), as model.train() does."""
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
-                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
+                        sd[p + ".weight"], sd[p + ".bias"], train, 0.1 if train else 0.0, eps)
 
 
 # ------------------------------------------------------------------ phase 2: 9 frequency bands
@@ -71,16 +73,16 @@ def frequency_bands(sd, lr):
 
 
 # ------------------------------------------------------------------ shared blocks
-def lka_block(sd, p, x):
+def lka_block(sd, p, x, train=False):
     """x + s1 * (n * sigmoid(BN(pw(dw21x1(dw1x21(dw5x5(n))))))), n = BN1(x); then + s2 * FFN(BN2(.))"""
     C = x.shape[1]
-    n = bn_eval(sd, p + "norm1", x)
+    n = bn_eval(sd, p + "norm1", x, train=train)
     a = conv(sd, p + "lka.local_conv", n, 2, groups=C)
     a = conv(sd, p + "lka.h_conv", a, (0, 10), groups=C)
     a = conv(sd, p + "lka.v_conv", a, (10, 0), groups=C)
-    a = torch.sigmoid(bn_eval(sd, p + "lka.bn", conv(sd, p + "lka.pw_conv", a)))
+    a = torch.sigmoid(bn_eval(sd, p + "lka.bn", conv(sd, p + "lka.pw_conv", a), train=train))
     x = x + sd[p + "scale1"] * (n * a)
-    f = conv(sd, p + "ffn.2", F.gelu(conv(sd, p + "ffn.0", bn_eval(sd, p + "norm2", x))))
+    f = conv(sd, p + "ffn.2", F.gelu(conv(sd, p + "ffn.0", bn_eval(sd, p + "norm2", x, train=train))))
     return x + sd[p + "scale2"] * f
 
 
@@ -96,7 +98,7 @@ def mha(sd, p, x, heads):
 
 
 # ------------------------------------------------------------------ phase 3
-def cross_band(sd, bands, p="cross_band."):
+def cross_band(sd, bands, p="cross_band.", train=False):
     B, _, H, W = bands[0].shape
     T = len(bands)
     proj = torch.stack([conv(sd, p + "band_proj", b) for b in bands], 1)        # [B,T,64,H,W]
@@ -104,11 +106,11 @@ def cross_band(sd, bands, p="cross_band."):
     seq = proj.permute(0, 3, 4, 1, 2).reshape(B * H * W, T, E)
     seq = seq + mha(sd, p + "band_attention.", F.layer_norm(seq, (E,), sd[p + "norm.weight"], sd[p + "norm.bias"]), 4)
     feat = seq.reshape(B, H, W, T, E).permute(0, 3, 4, 1, 2)
-    return [conv(sd, p + "out_proj", lka_block(sd, p + "lka_block.", feat[:, i])) + bands[i] for i in range(T)]
+    return [conv(sd, p + "out_proj", lka_block(sd, p + "lka_block.", feat[:, i], train)) + bands[i] for i in range(T)]
 
 
 # ------------------------------------------------------------------ phase 4
-def collaborative(sd, feats, imgs, p="collaborative."):
+def collaborative(sd, feats, imgs, p="collaborative.", train=False):
     al = [conv(sd, f"{p}align_layers.{n}", feats[n]) for n in EXPERTS]
     h, w = min(a.shape[2] for a in al), min(a.shape[3] for a in al)
     al = [a if a.shape[2:] == (h, w) else bilinear(a, (h, w)) for a in al]
@@ -122,9 +124,10 @@ def collaborative(sd, feats, imgs, p="collaborative."):
     enh = seq.reshape(B, h, w, T, E).permute(0, 3, 4, 1, 2)
     out = []
     for i, img in enumerate(imgs):
-        f = bilinear(lka_block(sd, p + "lka_global.", enh[:, i]), img.shape[2:])
+        f = bilinear(lka_block(sd, p + "lka_global.", enh[:, i], train), img.shape[2:])
         mod = torch.sigmoid(conv(sd, f"{p}modulation.{i}.2", F.gelu(conv(sd, f"{p}modulation.{i}.0", f))))
-        out.append((img * (1.0 + 0.2 * (mod - 0.5))).clamp(0, 1))
+        o = img * (1.0 + 0.2 * (mod - 0.5))
+        out.append(o if train else o.clamp(0, 1))          # large_kernel_attention.py:420-423: clamp at inference only
     return out
 
 
@@ -199,15 +202,18 @@ def laplacian_refine(sd, img, p="edge_enhance.", levels=3):
 
 
 # ------------------------------------------------------------------ whole pipeline
-def fusion_forward(sd, lr, imgs, feats, scale=4, return_stages=False):
-    """lr [B,3,h,w]; imgs/feats: dicts keyed drct/grl/nafnet/mamba -> final SR [B,3,4h,4w] in [0,1]."""
+def fusion_forward(sd, lr, imgs, feats, scale=4, return_stages=False, train=False):
+    """lr [B,3,h,w]; imgs/feats: dicts keyed drct/grl/nafnet/mamba -> final SR [B,3,4h,4w] in [0,1].
+    train=True: model.train() semantics with dropout off -- BatchNorm batch statistics (running statistics in ``sd``
+    updated in place), no clamp after the collaborative modulation and none on the result
+    (large_kernel_attention.py:420-423, enhanced_fusion_v2.py:792-795); differentiable w.r.t. the tensors of ``sd``."""
     B, _, h, w = lr.shape
     HR = (h * scale, w * scale)
     stages = {}
     bands = frequency_bands(sd, lr)
-    ebands = cross_band(sd, bands)
+    ebands = cross_band(sd, bands, train=train)
     routing = ebands[0] + ebands[1] + ebands[2]
-    enh = collaborative(sd, feats, [imgs[n] for n in EXPERTS])
+    enh = collaborative(sd, feats, [imgs[n] for n in EXPERTS], train=train)
     hier = hierarchical(sd, enh)
     logits = conv(sd, "freq_weight_conv.2", F.gelu(conv(sd, "freq_weight_conv.0", bilinear(routing, HR))))
     wts = logits.softmax(1)
@@ -223,7 +229,9 @@ def fusion_forward(sd, lr, imgs, feats, scale=4, return_stages=False):
         r = F.gelu(conv(sd, f"refine.{i}", r, 1))
     fused = fused + 0.1 * conv(sd, "refine.10", r, 1)
     edged = laplacian_refine(sd, fused)
-    out = (edged + sd["residual_scale"] * bilinear(lr, HR)).clamp(0, 1)
+    out = edged + sd["residual_scale"] * bilinear(lr, HR)
+    if not train:
+        out = out.clamp(0, 1)
     if return_stages:
         stages.update(bands=bands, ebands=ebands, routing=routing, enh=enh, hier=hier, fused_pre_refine=None,
                       refined=fused, edged=edged)

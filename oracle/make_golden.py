@@ -281,6 +281,58 @@ def golden_metrics():
                os.path.join(GOLDEN, "metrics.pt"))
 
 
+def train_case(seed, b, h, w):
+    """seeded cached-feature batch (SURVEY 8d config 5 pattern): lr, 4 expert images / features (fp16-exact), hr target"""
+    g = torch.Generator().manual_seed(seed)
+    lr = lr_input(seed, b, h, w)
+    bic = torch.nn.functional.interpolate(lr, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    imgs = {n: (bic + 0.03 * torch.randn(bic.shape, generator=g)).clamp(0, 1).half().float() for n in fusion.EXPERTS}
+    feats = {n: torch.randn(b, 64 if n == "nafnet" else 180, h, w, generator=g).half().float() for n in fusion.EXPERTS}
+    hr = (bic + 0.05 * torch.randn(bic.shape, generator=g)).clamp(0, 1)
+    return lr, imgs, feats, hr
+
+
+def golden_train():
+    """the reference's training-mode forward + backward (train.py:323-336) on a seeded batch ->
+    tests/golden/fusion_train.pt.  model.train() with the two nn.MultiheadAttention dropouts set to 0 (dropout
+    disabled); weights = the state_dict stored in fusion_full.pt (not stored again).
+    Stored: inputs, sr, loss = L1(sr.clamp(0,1), hr), the gradient of EVERY parameter, the BatchNorm running statistics
+    after the step's forward.  Also checks the oracle's train mode + torch autograd against the reference."""
+    ref = load_reference()
+    m = ref.CompleteEnhancedFusionSR(expert_ensemble=None)
+    missing = m.load_state_dict(load_sd(os.path.join(GOLDEN, "fusion_full.pt")), strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    m.train()
+    m.cross_band.band_attention.dropout = 0.0
+    m.collaborative.cross_attn.dropout = 0.0
+    lr, imgs, feats, hr = train_case(31, 2, 32, 32)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.endswith("num_batches_tracked")}
+    sr = m.forward_with_precomputed(lr, imgs, feats)
+    loss = torch.nn.functional.l1_loss(sr.clamp(0, 1), hr)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    stats = {k: v.detach().clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    # the oracle in train mode, differentiated by torch autograd
+    sdo = {k: (v.clone().requires_grad_(True) if k in grads else v.clone()) for k, v in sd0.items()}
+    sro = fusion.fusion_forward(sdo, lr, imgs, feats, train=True)
+    report("train-mode sr", sro.detach(), sr.detach(), 2e-5)
+    torch.nn.functional.l1_loss(sro.clamp(0, 1), hr).backward()
+    worst = 0.0
+    for k, gr in grads.items():
+        go = sdo[k].grad
+        assert go is not None, k
+        rel = (go - gr).abs().max().item() / max(gr.abs().max().item(), 1e-12)
+        worst = max(worst, rel)
+        assert rel < 2e-3, (k, rel)
+    print(f"  oracle autograd vs reference: worst per-tensor relative gradient error {worst:.2e} over {len(grads)} tensors")
+    for k, v in stats.items():
+        report(k, sdo[k].detach(), v, 1e-5)
+    torch.save({"lr": lr, "hr": hr, "imgs": {k: v.half() for k, v in imgs.items()}, "feats": {k: v.half() for k, v in feats.items()},
+                "sr": sr.detach(), "loss": loss.detach(), "grads": grads, "stats": stats},
+               os.path.join(GOLDEN, "fusion_train.pt"))
+    print(f"  fusion_train.pt: {os.path.getsize(os.path.join(GOLDEN, 'fusion_train.pt')) / 1e6:.2f} MB, loss {loss.item():.6f}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["inference", "metrics", "train"]
     if "inference" in what:

@@ -2,6 +2,11 @@ import importlib
 import os
 import sys
 
+# The CPU oracle (torch + one OpenMP C file) is the checker of every parity test.  A GPU box shows all of the host's cores
+# to the process but grants one GPU's share of them (16): 128 OpenMP threads on 16 cores run several times slower than 16.
+# Must be set before torch / libgomp initialise.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

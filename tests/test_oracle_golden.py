@@ -130,3 +130,27 @@ def test_u8_metrics_oracle_known_answers():
     assert abs(p - 20 * np.log10(255.0 / 5.0)) < 1e-12 and 0.9 < s < 1.0
     p4, _ = om.psnr_ssim_u8(a, a + 5, crop_border=4, test_y_channel=True)          # Y of a uniform +5 shift is +5 (+-1 rounding)
     assert abs(p4 - 20 * np.log10(255.0 / 5.0)) < 0.5
+
+
+def test_fusion_train_mode_oracle_matches_reference_forward_and_gradients():
+    """tests/golden/fusion_train.pt holds the reference's model.train() forward (dropout 0), the L1 loss and
+    loss.backward()'s gradient of every parameter (oracle/make_golden.py golden_train).  The oracle's train mode,
+    differentiated by torch autograd, must reproduce them: this is what pins the checker of the HIP backward pass."""
+    import torch.nn.functional as F
+    g, sd = load_golden("fusion_train.pt"), load_golden("fusion_full.pt")["sd"]
+    sdo = {k: (v.clone().requires_grad_(True) if k in g["grads"] else v.clone()) for k, v in sd.items()}
+    imgs, feats = {k: v.float() for k, v in g["imgs"].items()}, {k: v.float() for k, v in g["feats"].items()}
+    sr = fusion.fusion_forward(sdo, g["lr"], imgs, feats, train=True)
+    _close(sr.detach(), g["sr"], 2e-5)
+    loss = F.l1_loss(sr.clamp(0, 1), g["hr"])
+    assert abs(loss.item() - g["loss"].item()) < 1e-6
+    loss.backward()
+    assert len(g["grads"]) == 198 and sum(v.numel() for v in g["grads"].values()) == 1433217
+    for k, want in g["grads"].items():
+        err = (sdo[k].grad - want).abs().max().item()
+        assert err <= 1e-3 * want.abs().max().item() + 1e-12, (k, err)
+    for k, want in g["stats"].items():
+        _close(sdo[k].detach(), want, 1e-5)
+    # eval mode is untouched by the train flag's plumbing: the clamps are back
+    with torch.no_grad():
+        assert fusion.fusion_forward(sd, g["lr"], imgs, feats).max().item() <= 1.0
