@@ -67,8 +67,66 @@ def cpu_baseline(weights, naf_cfg=None, tiles=5):
             "sample": f"{tiles} x 64x64 LR tiles -> 256x256 ({mp:.3f} MP), 4 experts + fusion, {dt:.1f} s of CPU work after one warm-up tile"}
 
 
+def train_bench(args):
+    """BASELINE config 5 (`--config train`): ONE cached-feature training step of the fusion network per "step" --
+    forward_with_precomputed in train mode on a batch of 32 cached 64x64 LR patches (seeded expert images / features
+    resident in HBM), L1 loss after clamp, backward through all 1.43 M parameters, clip_grad_norm_(1.0), AdamW(2e-4,
+    wd 1e-4), EMA(0.999): train.py:297-359 of the reference.  Frozen experts are NOT run (their outputs are the cache,
+    exactly as in the reference's cached loop); attention dropout is off.  Single GPU by definition."""
+    W = importlib.import_module("image-super-resolution_amd.weights")
+    E = importlib.import_module("image-super-resolution_amd.engine")
+    T = importlib.import_module("image-super-resolution_amd.train")
+    ops = importlib.import_module("image-super-resolution_amd.ops")
+    if args.gemm:
+        ops.set_gemm_mode(args.gemm)
+    if args.gpus != 1:
+        raise SystemExit("--config train is a single-GPU configuration (BASELINE config 5)")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    B, h, w = args.batch if args.batch > 1 else 32, 64, 64
+    g = torch.Generator().manual_seed(4321)
+    sd = {k: v for k, v in W.fusion_state_dict(seed=0).items() if v.is_floating_point() and v.numel() > 0}
+    tr = T.FusionTrainer(sd, device)
+    lr = synth_lr(99, h, w, B)
+    bic = torch.nn.functional.interpolate(lr, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    names = ("drct", "grl", "nafnet", "mamba")
+    imgs = {n: E.nchw_to_map((bic + 0.03 * torch.randn(bic.shape, generator=g)).clamp(0, 1), device) for n in names}
+    feats = {n: E.nchw_to_map(torch.randn(B, 64 if n == "nafnet" else 180, h, w, generator=g), device) for n in names}
+    hr = E.nchw_to_map(torch.rand(B, 3, 4 * h, 4 * w, generator=g), device)
+    lrm = E.nchw_to_map(lr, device)
+    T0 = time.perf_counter()
+    for i in range(args.warmup):
+        tr.step(lrm, hr, imgs, feats)
+        torch.cuda.synchronize(device)
+        print(f"[bench +{time.perf_counter() - T0:6.1f}s] warm-up training step {i} done", file=sys.stderr, flush=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = tr.step(lrm, hr, imgs, feats)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    # SURVEY 8d: fusion forward 116.3 GFLOP per 64x64 tile (112.8 conv/GEMM + 3.5 MHA); backward = input + weight gradient
+    tflop = 3 * B * (h * w / 4096.0) * 116.3e9 / 1e12
+    peak = MFMA_F32_PEAK_TFLOPS if ops.GEMM_MODE == "f32" else MFMA_BF16_PEAK_TFLOPS / 3.0
+    line = {"metric": f"cached-feature training steps/s (BASELINE config 5: {B} x {w}x{h} LR patches, fusion net fwd + bwd + AdamW)",
+            "value": args.steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (conv products as 3-term split-bf16 MFMA; weight gradients on the exact f32 MFMA)",
+            "data": "synthetic (seeded cached expert images / features / HR targets; random-init fusion weights)",
+            "config": {"workload": f"train_epoch_cached step: forward_with_precomputed(train) + L1 + backward + clip + AdamW + EMA, "
+                                   f"batch {B} of {w}x{h} LR patches -> {4 * w}x{4 * h}", "patches_per_step": B,
+                       "patches_per_s": B * args.steps / dt, "attention_dropout": 0.0},
+            "gemm_mode": ops.GEMM_MODE, "final_loss": float(loss.item()),
+            "roofline": {"bound": "mfma", "achieved": tflop / (dt / args.steps), "peak": peak, "unit": "TFLOP/s",
+                         "frac": tflop / (dt / args.steps) / peak, "traffic": None,
+                         "note": "whole step: algorithmic 3 x forward FLOPs (SURVEY 8d) / step time, not a single kernel"}}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["infer", "train"], default="infer",
+                    help="infer: BASELINE's headline metric (default); train: BASELINE config 5, one cached-feature training step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -82,6 +140,8 @@ def main():
     ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=None, help="GEMM arithmetic (default: the engine's default)")
     args = ap.parse_args()
+    if args.config == "train":
+        return train_bench(args)
 
     W = importlib.import_module("image-super-resolution_amd.weights")
     E = importlib.import_module("image-super-resolution_amd.engine")

@@ -386,26 +386,59 @@ def test_fusion_train_step_against_reference_fixture(mode):
         ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
 
 
-def test_fusion_gradients_and_full_step_vs_oracle_autograd_64x64():
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_fusion_gradients_and_full_step_vs_oracle_autograd_64x64(mode):
     """B = 2 at 64x64 -- HIP gradients of all 1.43 M parameters against torch-CPU autograd through
     oracle/ffsr_oracle/fusion.py (train mode), then ONE full step (loss -> grads -> clip_grad_norm_ -> AdamW -> EMA,
-    train.py:323-359) against oracle/ffsr_oracle/train.py's Trainer fed with the oracle's gradients."""
+    train.py:323-359) against oracle/ffsr_oracle/train.py's Trainer fed with the oracle's gradients.
+    Modes: f32 = exact f32-MFMA convolutions (the arithmetic class of the reference's CPU path) -> 1e-3 per tensor;
+    bf16x3 (default) = 1e-5-relative products: a ReLU / clamp whose argument is within that distance of 0 flips its mask,
+    and one flipped unit of the selector's 3x3 convs moves a weight gradient by ~1 / (number of pixels) -> 3e-3 per tensor
+    (measured: 1.9e-3 on dynamic_selector.gate_net.0.weight, everything else <= 1.5e-3)."""
     from ffsr_oracle import fusion as ofusion, train as otrain
     from make_golden import train_case
-    T, W, FT = mod("train"), mod("weights"), mod("fusion_train")
+    T, W, FT, ops = mod("train"), mod("weights"), mod("fusion_train"), mod("ops")
+    ops.set_gemm_mode(mode)
+    try:
+        _full_step_case(mode, ofusion, otrain, train_case, T, W, FT)
+    finally:
+        ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
+
+
+def _full_step_case(mode, ofusion, otrain, train_case, T, W, FT):
     sd = {k: v for k, v in W.fusion_state_dict(seed=5).items() if v.is_floating_point() and v.numel() > 0}
     lr, imgs, feats, hr = train_case(77, 2, 64, 64)
     case = {"lr": lr, "hr": hr, "imgs": imgs, "feats": feats}
     names = [k for k in sd if FT.is_parameter(k)]
-    sdo = {k: (v.clone().float().requires_grad_(True) if k in names else v.clone().float()) for k, v in sd.items()}
-    sro = ofusion.fusion_forward(sdo, lr, imgs, feats, train=True)
-    loss_o = F.l1_loss(sro.clamp(0, 1), hr)
-    loss_o.backward()
-    want = {k: sdo[k].grad for k in names}
+
+    def oracle_grads(dt):
+        s_ = {k: (v.clone().to(dt).requires_grad_(True) if k in names else v.clone().to(dt)) for k, v in sd.items()}
+        sr_ = ofusion.fusion_forward(s_, lr.to(dt), {k: v.to(dt) for k, v in imgs.items()}, {k: v.to(dt) for k, v in feats.items()},
+                                     train=True)
+        l_ = F.l1_loss(sr_.clamp(0, 1), hr.to(dt))
+        l_.backward()
+        return l_.item(), {k: s_[k].grad for k in names}
+
+    # With these weights several gradients are sums with heavy cancellation (|g| ~ 1e-7): torch's OWN fp32 autograd is up to
+    # 1.6e-3 (relative, per tensor) away from the float64 evaluation of the same graph.  So the truth is the float64 oracle,
+    # and the HIP gradient may deviate from it by 1e-3 plus twice what fp32 CPU autograd (the reference's arithmetic) does.
+    loss_o, want = oracle_grads(torch.float32)
+    _, truth = oracle_grads(torch.float64)
     tr = T.FusionTrainer(sd, DEV)
-    loss = tr.step(*(_train_inputs(case)[i] for i in (0, 1, 2, 3)))
-    assert abs(loss.item() - loss_o.item()) < 1e-5
-    bad = _grad_report(tr, want, 1e-3, floor=1e-12)
+    loss = tr.step(*_train_inputs(case))
+    assert abs(loss.item() - loss_o) < 1e-5
+    got = tr.opt.views(tr.opt.grad)
+    rows = []
+    for k in names:
+        scale = max(truth[k].abs().max().item(), 1e-30)
+        e_hip = (got[k].cpu().double() - truth[k]).abs().max().item() / scale
+        e_cpu = (want[k].double() - truth[k]).abs().max().item() / scale
+        rows.append((e_hip, e_cpu, k, scale))
+    rows.sort(reverse=True)
+    print("worst per-tensor relative gradient error vs the float64 oracle (hip, torch-fp32-cpu):",
+          [(f"{a:.1e}", f"{b:.1e}", k, f"|g|max {m:.1e}") for a, b, k, m in rows[:6]])
+    tol = 1e-3 if mode == "f32" else 3e-3
+    bad = [(k, a, b) for a, b, k, m in rows if a > tol + 2 * b and a * m > 1e-12]
     assert not bad, bad
     # (a) the optimiser pipeline itself: torch's clip_grad_norm_ + AdamW + EMA fed with the HIP gradients -> tight agreement
     hip_grads = {k: v.cpu().clone() for k, v in tr.opt.views(tr.opt.grad).items()}
