@@ -167,7 +167,7 @@ class Tape:
     def coldot_into(self, dst: torch.Tensor, a, b=None, ostride=1, scale=1.0):
         """dst[c * ostride] += scale * sum_m a[m, c] * b[m, c]"""
         _, M, C, lda = _mat(a)
-        nchunk = max(1, min(2048, M // 256))
+        nchunk = max(1, min(512, M // 256))
         part = torch.empty(nchunk * C, device=self.device)
         hip.call("ffsr_coldot_acc_f32", _ptr(a), lda, _ptr(b), 0 if b is None else _mat(b)[3], M, C, _ptr(part), nchunk,
                  _ptr(dst), ostride, float(scale), 1, _stream())
@@ -241,10 +241,9 @@ class Tape:
                 gz = _zero_padded(gy, p.N, self.device)  # the dgrad GEMM contracts over pad4(N) aligned channels: pad = 0
             else:
                 gz = gy
-            if p.bias is not None:
-                self.coldot_into(p.bias.g, gz)
-            part = torch.empty(max(p.weight.v.numel() * 64, 1 << 20), device=self.device)
-            hip.call("ffsr_conv_wgrad_f32", _ptr(xm), ops.ld(xm), _ptr(gz), ops.ld(gz), _ptr(p.weight.g), _ptr(part),
+            part = torch.empty(max((p.weight.v.numel() + p.N) * 256, 1 << 20), device=self.device)   # room for up to 256 pixel splits
+            hip.call("ffsr_conv_wgrad_f32", _ptr(xm), ops.ld(xm), _ptr(gz), ops.ld(gz), _ptr(p.weight.g),
+                     None if p.bias is None else _ptr(p.bias.g), _ptr(part),
                      part.numel(), B, H, W, p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
             if x.req:
                 gx = ops.conv2d(ops.widen(gz, p.bwd.Cin), p.bwd, tile_hint=conv_tile(M, p.Cin, p.KH * p.KW))

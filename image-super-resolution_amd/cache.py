@@ -94,3 +94,92 @@ def collate(entries: List[Dict[str, object]]) -> Dict[str, object]:
     if "expert_feats" in entries[0]:
         out["expert_feats"] = {k: torch.stack([e["expert_feats"][k] for e in entries]) for k in entries[0]["expert_feats"]}
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 8x geometric-TTA test cache + cached submission: scripts/extract_test_tta_cache.py:248-330 writes, per
+# test image and per variant t0..t7 = {hflip} x {rot90^k}, the same three part files -- every tensor fp16, the drct part
+# also carries the transformed LR, the original size and the transform; scripts/generate_fast_submission.py:188-256 reads
+# them back, runs ONLY the fusion network per variant, undoes the transform, averages and clamps.
+TTA_CONFIGS = tuple((hflip, rot) for hflip in (False, True) for rot in (0, 1, 2, 3))      # extract_test_tta_cache.py:253-256
+
+
+def tta_stem(lr_path_or_stem: str) -> str:
+    """'0901x4.png' -> '0901' (extract_test_tta_cache.py:264-265)"""
+    raw = os.path.splitext(os.path.basename(str(lr_path_or_stem)))[0]
+    return raw.replace("x4", "").rstrip("_")
+
+
+def extract_tta(engine, lr: torch.Tensor, cache_dir, stem: str, resume: bool = False) -> int:
+    """lr [1,3,h,w] float (host) -> the 24 part files {stem}_t{0..7}_{drct,rest,mamba}_part.pt.  Each variant is the
+    transformed LR image through Engine.run_experts (pad16 -> four experts -> crops / clamps / NAFNet feature resample),
+    stored as fp16 like the reference (run_expert_sequential :108-177).  Returns the number of variants written."""
+    from . import engine as E, ops
+    os.makedirs(str(cache_dir), exist_ok=True)
+    half = lambda t: t.detach().to("cpu").half().contiguous()
+    base = E.nchw_to_map(lr, engine.device)
+    written = 0
+    for t_idx, (hflip, rot) in enumerate(TTA_CONFIGS):
+        t_stem = f"{stem}_t{t_idx}"
+        if resume and os.path.exists(_path(cache_dir, t_stem, "drct")):
+            continue
+        variant = ops.dihedral(base, hflip, rot)
+        imgs, feats = engine.run_experts(variant)
+        torch.cuda.current_stream(engine.device).synchronize()
+        out = {k: half(E.map_to_nchw(v[..., :3])) for k, v in imgs.items()}
+        ft = {k: half(E.map_to_nchw(v)) for k, v in feats.items()}
+        lr_v = E.map_to_nchw(variant)
+        torch.save({"outputs": {"drct": out["drct"]}, "features": {"drct": ft["drct"]}, "lr": half(lr_v[0]), "filename": t_stem,
+                    "original_stem": stem, "original_size": (int(lr_v.shape[2]), int(lr_v.shape[3])),
+                    "tta_info": {"hflip": bool(hflip), "rot": int(rot), "t_idx": t_idx}}, _path(cache_dir, t_stem, "drct"))
+        torch.save({"outputs": {k: out[k] for k in ("grl", "nafnet")}, "features": {k: ft[k] for k in ("grl", "nafnet")},
+                    "filename": t_stem}, _path(cache_dir, t_stem, "rest"))
+        torch.save({"outputs": {"mamba": out["mamba"]}, "features": {"mamba": ft["mamba"]}, "filename": t_stem},
+                   _path(cache_dir, t_stem, "mamba"))
+        written += 1
+    return written
+
+
+def list_tta_stems(cache_dir) -> List[str]:
+    """unique image stems of a TTA cache (generate_fast_submission.py:174-176)"""
+    return sorted(f[:-len("_t0_drct_part.pt")] for f in os.listdir(str(cache_dir)) if f.endswith("_t0_drct_part.pt"))
+
+
+def fuse_tta(engine, cache_dir, stem: str, num_variants: int = 8) -> torch.Tensor:
+    """generate_fast_submission.py:200-250 for one image: every cached variant through the fusion network only
+    (Engine.fusion = forward_with_precomputed), inverse transform, mean over the variants found, clamp.
+    -> SR map [1,4h,4w,3] on the device.  Files are read with weights_only=True."""
+    from . import engine as E, ops
+    acc, n = None, 0
+    maps = []
+    for t_idx in range(num_variants):
+        t_stem = f"{stem}_t{t_idx}"
+        if not os.path.exists(_path(cache_dir, t_stem, "drct")):
+            continue                                                  # the reference warns and skips (:212-214)
+        d, r, m = (torch.load(_path(cache_dir, t_stem, p), map_location="cpu", weights_only=True) for p in PARTS)
+        info = d.get("tta_info", {"hflip": False, "rot": 0})
+        dev_map = lambda t: E.nchw_to_map(t.float() if t.dim() == 4 else t.float().unsqueeze(0), engine.device)
+        imgs = {"drct": dev_map(d["outputs"]["drct"]), "grl": dev_map(r["outputs"]["grl"]),
+                "nafnet": dev_map(r["outputs"]["nafnet"]), "mamba": dev_map(m["outputs"]["mamba"])}
+        feats = {"drct": dev_map(d["features"]["drct"]), "grl": dev_map(r["features"]["grl"]),
+                 "nafnet": dev_map(r["features"]["nafnet"]), "mamba": dev_map(m["features"]["mamba"])}
+        sr = engine.fusion(dev_map(d["lr"]), imgs, feats)
+        maps.append((sr, bool(info["hflip"]), int(info["rot"])))
+    if not maps:
+        raise FileNotFoundError(f"no cached TTA variants of {stem!r} in {cache_dir}")
+    for sr, hflip, rot in maps:                                       # mean of the de-transformed outputs, then clamp (:245)
+        acc = ops.dihedral(sr, hflip, rot, inverse=True, out=acc, scale=1.0 / len(maps), accumulate=acc is not None)
+    return ops.unary(acc, clamp=(0.0, 1.0), out=acc)
+
+
+def generate_submission(engine, cache_dir, output_dir, no_tta: bool = False) -> List[str]:
+    """the image loop of generate_fast_submission.py:188-256: one '{stem}x4.png' per cached test image"""
+    from PIL import Image
+    os.makedirs(str(output_dir), exist_ok=True)
+    names = []
+    for stem in list_tta_stems(cache_dir):
+        sr = fuse_tta(engine, cache_dir, stem, 1 if no_tta else 8)
+        name = f"{stem}x4.png"                                        # NTIRE naming (:248-251)
+        Image.fromarray(engine.download(sr)).save(os.path.join(str(output_dir), name), compress_level=1)
+        names.append(name)
+    return names

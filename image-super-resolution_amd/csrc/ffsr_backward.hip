@@ -73,17 +73,29 @@ __device__ __forceinline__ float act_grad(float r, int act, float slope, int fro
     default: return 1.f;
   }
 }
-// dx = (accumulate ? dx : 0) + alpha * dy * act'(ref)
+// dx = (accumulate ? dx : 0) + alpha * dy * act'(ref);  V = 4: C % 4 == 0 and 16-byte aligned rows
+template <int V>
 __global__ void act_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ ref, int ldr,
                                float* __restrict__ dx, int ldx, long long M, int C, int act, float slope, int from_output,
                                float alpha, int accumulate) {
+  const int cv = C / V;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * C) return;
-  const long long m = idx / C;
-  const int c = (int)(idx - m * C);
-  const float g = alpha * dy[m * ldy + c] * act_grad(ref[m * ldr + c], act, slope, from_output);
-  float* o = dx + m * ldx + c;
-  *o = accumulate ? *o + g : g;
+  if (idx >= M * cv) return;
+  const long long m = idx / cv;
+  const int c = (int)(idx - m * cv) * V;
+  if constexpr (V == 4) {
+    const floatx4 g = *reinterpret_cast<const floatx4*>(dy + m * ldy + c);
+    const floatx4 r = *reinterpret_cast<const floatx4*>(ref + m * ldr + c);
+    floatx4 o = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) o = *reinterpret_cast<const floatx4*>(dx + m * ldx + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] += alpha * g[i] * act_grad(r[i], act, slope, from_output);
+    *reinterpret_cast<floatx4*>(dx + m * ldx + c) = o;
+  } else {
+    const float g = alpha * dy[m * ldy + c] * act_grad(ref[m * ldr + c], act, slope, from_output);
+    float* o = dx + m * ldx + c;
+    *o = accumulate ? *o + g : g;
+  }
 }
 
 // out = alpha * (sa ? sa[0] : 1) * a + beta * (sb ? sb[0] : 1) * b   (b optional; sa / sb = learnable device scalars)
@@ -159,26 +171,47 @@ __global__ __launch_bounds__(RB) void coldot_partial_kernel(const float* __restr
   if (rl == 0 && c < C)
     part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// out[c * ostride] = (accumulate ? out : 0) + scale * sum_k part[k * pstride + c]   (double accumulation); one thread per column
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int nchunk, int pstride, int C, float* __restrict__ out,
-                                     int ostride, float scale, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * pstride + c];
-  float* o = out + (size_t)c * ostride;
-  *o = (accumulate ? *o : 0.f) + (float)(scale * s);
+// out[c * ostride] = (accumulate ? out : 0) + scale * sum_k part[k * pstride + c]   (double accumulation)
+// block 256 = 64 columns x 4 chunk lanes, grid = ceil(C / 64)
+__global__ __launch_bounds__(RB) void colsum_finish_kernel(const float* __restrict__ part, int nchunk, int pstride, int C,
+                                                           float* __restrict__ out, int ostride, float scale, int accumulate) {
+  __shared__ double red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int kl = threadIdx.x >> 6;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    int k = kl;
+    for (; k + 4 < nchunk; k += 8) {
+      s0 += part[(size_t)k * pstride + c];
+      s1 += part[(size_t)(k + 4) * pstride + c];
+    }
+    for (; k < nchunk; k += 4) s0 += part[(size_t)k * pstride + c];
+  }
+  red[kl][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (kl == 0 && c < C) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* o = out + (size_t)c * ostride;
+    *o = (accumulate ? *o : 0.f) + (float)(scale * s);
+  }
 }
 
-// out[m * ldo] = alpha * sum_c a[m, c] * b[m, c]     (gradient of a row-broadcast factor); one thread per row
-__global__ void rowdot_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ out,
-                              int ldo, long long M, int C, float alpha, int accumulate) {
-  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+// out[m * ldo] = alpha * sum_c a[m, c] * b[m, c]     (gradient of a row-broadcast factor); LPR lanes per row so that a wave
+// reads whole rows contiguously
+template <int LPR>
+__global__ __launch_bounds__(RB) void rowdot_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                    float* __restrict__ out, int ldo, long long M, int C, float alpha, int accumulate) {
+  const long long m = ((long long)blockIdx.x * RB + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s = fmaf(a[m * lda + c], b[m * ldb + c], s);
-  float* o = out + m * ldo;
-  *o = (accumulate ? *o : 0.f) + alpha * s;
+  if (m < M)
+    for (int c = l; c < C; c += LPR) s = fmaf(a[m * lda + c], b[m * ldb + c], s);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (m < M && l == 0) {
+    float* o = out + m * ldo;
+    *o = (accumulate ? *o : 0.f) + alpha * s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm2d (train mode)
@@ -295,38 +328,50 @@ __global__ __launch_bounds__(RB) void layernorm_bwd_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------- depthwise conv weight grad
 // part[chunk, t, c] = sum over the pixels of the chunk of dy[pix, c] * x[pix + offset(t), c]   (zero padding)
-// grid (ceil(C / 64), nchunk), block 256 = 64 channels x 4 pixel lanes; T = KH * KW <= 25
+// grid (ceil(C / 64), nchunk), block 256 = 64 channels x 4 pixel lanes; KH x KW compile-time (5x5, 1x21, 21x1 of the LKA
+// chain, large_kernel_attention.py:58-76); every tap has its own accumulator register.
+template <int KH, int KW>
 __global__ __launch_bounds__(RB) void dwconv_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int ldy,
-                                                          float* __restrict__ part, int B, int H, int W, int C, int KH, int KW,
-                                                          int ph, int pw, int nchunk) {
+                                                          float* __restrict__ part, int B, int H, int W, int C, int ph, int pw,
+                                                          int nchunk) {
+  constexpr int T = KH * KW;
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int pl = threadIdx.x >> 6;
   const long long P = (long long)B * H * W, per = (P + nchunk - 1) / nchunk;
   const long long p0 = blockIdx.y * per, p1 = (p0 + per < P) ? p0 + per : P;
-  const int T = KH * KW;
-  float acc[25];
+  float acc[T];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) acc[t] = 0.f;
-  if (c < C) {
-    for (long long p = p0 + pl; p < p1; p += 4) {
-      const int xx = (int)(p % W);
-      const int yy = (int)((p / W) % H);
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  if (c < C && p0 + pl < p1) {
+    long long p = p0 + pl;
+    int xx = (int)(p % W), yy = (int)((p / W) % H);
+    for (; p < p1; p += 4) {
       const float g = dy[p * ldy + c];
+      const float* xc = x + p * ldx + c;
 #pragma unroll
-      for (int t = 0; t < 25; ++t) {
-        if (t < T) {
-          const int sy = yy + t / KW - ph, sx = xx + t % KW - pw;
-          if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc[t] = fmaf(g, x[(p + (long long)(sy - yy) * W + (sx - xx)) * ldx + c], acc[t]);
+      for (int ky = 0; ky < KH; ++ky) {
+        const int sy = yy + ky - ph;
+        const bool yok = sy >= 0 && sy < H;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int sx = xx + kx - pw;
+          const bool ok = yok && sx >= 0 && sx < W;
+          const long long off = ((long long)(ky - ph) * W + (kx - pw)) * ldx;
+          const float v = ok ? xc[off] : 0.f;
+          acc[ky * KW + kx] = fmaf(g, v, acc[ky * KW + kx]);
         }
+      }
+      xx += 4;
+      while (xx >= W) {
+        xx -= W;
+        if (++yy == H) yy = 0;
       }
     }
   }
-  for (int t = 0; t < T; ++t) {
-    float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < 25; ++q) v = (q == t) ? acc[q] : v;
-    red[pl][threadIdx.x & 63] = v;
+  for (int t = 0; t < T; ++t) {
+    red[pl][threadIdx.x & 63] = acc[t];
     __syncthreads();
     if (pl == 0 && c < C)
       part[((size_t)blockIdx.y * T + t) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -639,8 +684,13 @@ extern "C" int ffsr_act_bwd_f32(const float* dy, int ldy, const float* ref, int 
                                 int act, float slope, int from_output, float alpha, int accumulate, void* stream) {
   FFSR_CHECK(dy && ref && dx && M > 0 && C > 0 && ldy >= C && ldr >= C && ldx >= C && act >= 0 && act <= 7);
   FFSR_CHECK(!from_output || act == FFSR_ACT_RELU || act == FFSR_ACT_LRELU || act == FFSR_ACT_SIGMOID || act == FFSR_ACT_NONE);
-  FFSR_LAUNCH(act_bwd_kernel, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, ref, ldr, dx, ldx, M, C, act, slope,
-              from_output, alpha, accumulate);
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (C % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && ldx % 4 == 0 && al16(dy) && al16(ref) && al16(dx))
+    FFSR_LAUNCH(act_bwd_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(RB), 0, ST, dy, ldy, ref, ldr, dx, ldx, M, C, act, slope,
+                from_output, alpha, accumulate);
+  else
+    FFSR_LAUNCH(act_bwd_kernel<1>, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, ref, ldr, dx, ldx, M, C, act, slope,
+                from_output, alpha, accumulate);
   return ffsr_launch_status();
 }
 
@@ -666,14 +716,19 @@ extern "C" int ffsr_coldot_acc_f32(const float* a, int lda, const float* b, int 
                                    int nchunk, float* out, int ostride, float scale, int accumulate, void* stream) {
   FFSR_CHECK(a && part && out && M > 0 && C > 0 && lda >= C && (!b || ldb >= C) && nchunk >= 1 && nchunk <= 65535 && ostride >= 1);
   FFSR_LAUNCH(coldot_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(RB), 0, ST, a, lda, b, ldb, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part, nchunk, C, C, out, ostride, scale, accumulate);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, out, ostride, scale, accumulate);
   return ffsr_launch_status();
 }
 
 extern "C" int ffsr_rowdot_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo, long long M, int C,
                                float alpha, int accumulate, void* stream) {
   FFSR_CHECK(a && b && out && M > 0 && C > 0 && lda >= C && ldb >= C && ldo >= 1);
-  FFSR_LAUNCH(rowdot_kernel, dim3(grid_for(M)), dim3(RB), 0, ST, a, lda, b, ldb, out, ldo, M, C, alpha, accumulate);
+  if (C >= 48)
+    FFSR_LAUNCH(rowdot_kernel<32>, dim3(grid_for(M * 32)), dim3(RB), 0, ST, a, lda, b, ldb, out, ldo, M, C, alpha, accumulate);
+  else if (C >= 12)
+    FFSR_LAUNCH(rowdot_kernel<8>, dim3(grid_for(M * 8)), dim3(RB), 0, ST, a, lda, b, ldb, out, ldo, M, C, alpha, accumulate);
+  else
+    FFSR_LAUNCH(rowdot_kernel<1>, dim3(grid_for(M)), dim3(RB), 0, ST, a, lda, b, ldb, out, ldo, M, C, alpha, accumulate);
   return ffsr_launch_status();
 }
 
@@ -687,9 +742,9 @@ extern "C" int ffsr_bn_train_stats_f32(const float* x, int ldx, long long M, int
   FFSR_CHECK(!run_mean == !run_var);
   const dim3 g((C + 63) / 64, nchunk);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, (const float*)nullptr, 0, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, x, ldx, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
   FFSR_LAUNCH(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, sums, M, C, gamma, beta, eps, momentum, stat,
               scale_shift, run_mean, run_var);
   return ffsr_launch_status();
@@ -704,9 +759,9 @@ extern "C" int ffsr_bn_train_bwd_f32(const float* x, int ldx, const float* dy, i
              ldy >= C && lddx >= C && nchunk >= 1 && nchunk <= 65535);
   const dim3 g((C + 63) / 64, nchunk);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, (const float*)nullptr, 0, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, x, ldx, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
   FFSR_LAUNCH(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, sums, M, C, gamma, stat, coef, dgamma, dbeta);
   FFSR_LAUNCH(affine2_kernel, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, x, ldx, coef, dx, lddx, M, C);
   return ffsr_launch_status();
@@ -722,8 +777,8 @@ extern "C" int ffsr_layernorm_bwd_f32(const float* x, int ldx, const float* gamm
   long long rpb = (M + nblock - 1) / nblock;
   const int nb = (int)((M + rpb - 1) / rpb);
   FFSR_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(RB), 0, ST, x, ldx, gamma, dy, ldy, dx, lddx, part, M, C, eps, rpb);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part, nb, 2 * C, C, dgamma, 1, 1.f, 1);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, part + C, nb, 2 * C, C, dbeta, 1, 1.f, 1);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nb, 2 * C, C, dgamma, 1, 1.f, 1);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part + C, nb, 2 * C, C, dbeta, 1, 1.f, 1);
   return ffsr_launch_status();
 }
 
@@ -731,10 +786,18 @@ extern "C" int ffsr_layernorm_bwd_f32(const float* x, int ldx, const float* gamm
 // part: scratch of nchunk * KH * KW * C floats.
 extern "C" int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* part, int nchunk, int B,
                                      int H, int W, int C, int KH, int KW, int pad_h, int pad_w, void* stream) {
-  FFSR_CHECK(x && dy && dw && part && B > 0 && H > 0 && W > 0 && C > 0 && KH * KW >= 1 && KH * KW <= 25 && ldx >= C && ldy >= C &&
-             nchunk >= 1 && nchunk <= 65535);
-  FFSR_LAUNCH(dwconv_wgrad_kernel, dim3((C + 63) / 64, nchunk), dim3(RB), 0, ST, x, ldx, dy, ldy, part, B, H, W, C, KH, KW,
-              pad_h, pad_w, nchunk);
+  FFSR_CHECK(x && dy && dw && part && B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && ldy >= C && nchunk >= 1 && nchunk <= 65535);
+  const dim3 g((C + 63) / 64, nchunk);
+  if (KH == 5 && KW == 5)
+    FFSR_LAUNCH((dwconv_wgrad_kernel<5, 5>), g, dim3(RB), 0, ST, x, ldx, dy, ldy, part, B, H, W, C, pad_h, pad_w, nchunk);
+  else if (KH == 1 && KW == 21)
+    FFSR_LAUNCH((dwconv_wgrad_kernel<1, 21>), g, dim3(RB), 0, ST, x, ldx, dy, ldy, part, B, H, W, C, pad_h, pad_w, nchunk);
+  else if (KH == 21 && KW == 1)
+    FFSR_LAUNCH((dwconv_wgrad_kernel<21, 1>), g, dim3(RB), 0, ST, x, ldx, dy, ldy, part, B, H, W, C, pad_h, pad_w, nchunk);
+  else if (KH == 3 && KW == 3)
+    FFSR_LAUNCH((dwconv_wgrad_kernel<3, 3>), g, dim3(RB), 0, ST, x, ldx, dy, ldy, part, B, H, W, C, pad_h, pad_w, nchunk);
+  else
+    return FFSR_EINVAL;
   FFSR_LAUNCH(dwconv_wgrad_finish_kernel, dim3(grid_for((long long)KH * KW * C)), dim3(RB), 0, ST, part, nchunk, KH * KW, C, dw);
   return ffsr_launch_status();
 }

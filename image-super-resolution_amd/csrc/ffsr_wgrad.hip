@@ -9,13 +9,15 @@
 // are therefore plain ds_read_b32 of consecutive floats of a staged [pixel][channel] tile: no transposes anywhere
 // (a bf16 MFMA would need k = 8 consecutive pixels per lane, a transpose of both operands).  Products are exact fp32.
 //
-// grid = (row tiles x column tiles, taps, pixel splits); one workgroup = 4 waves arranged WN x WC x WK over a
+// grid = row tiles x column tiles x taps x pixel splits (flattened, XCD-aware order); one workgroup = 4 waves arranged WN x WC x WK over a
 // (32 FN WN) x (32 FC WC) tile of (n, c): waves along WK take alternate pixel pairs of a staged chunk and are summed
 // through LDS at the end.  Chunks of 16 pixels are double buffered (global -> registers -> LDS, one barrier per chunk);
-// per-pixel validity of the shifted tap (image borders, end of the split) is computed two chunks ahead by 16 threads.
+// per-pixel validity of the shifted tap (image borders, end of the split) is computed two chunks ahead by the first wave
+// (one ballot -> a 16-bit mask per operand).
 // Every split writes its partial tile; a second kernel sums the splits in double precision and ACCUMULATES into dW in
 // nn.Conv2d layout [N, Cin, KH, KW] (deterministic, no atomics).
 #include "ffsr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -25,13 +27,14 @@ struct WgradArgs {
   const float* x;
   const float* dy;
   float* part;
+  float* bias_part;     // [splits][N] column sums of dY (bias gradient) or null
   int ldx, ldy;
   int B, H, W, Cin, N, KH, KW, ph, pw;
   long long P, per_split;
   int n_tiles, c_tiles;
 };
 
-template <int WN, int WC, int FN, int FC>
+template <int WN, int WC, int FN, int FC, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int WK = 4 / (WN * WC);
   constexpr int TN = 32 * FN * WN, TC = 32 * FC * WC;
@@ -40,66 +43,92 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int RED = (WK > 1) ? WK * TN * TC : 0;
   constexpr int LDS_FLOATS = (2 * STAGE > RED) ? 2 * STAGE : RED;
   __shared__ float lds[LDS_FLOATS];
-  __shared__ int meta[2][2][KC];                            // [slot][0: dY row valid, 1: X row valid][pixel of the chunk]
+  __shared__ unsigned meta[2][2];                           // [slot][0: dY rows valid, 1: X rows valid]: bit k = pixel k of the chunk
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wk = wave % WK, wc = (wave / WK) % WC, wn = wave / (WK * WC);
-  const int tile = blockIdx.x;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  All (tile, tap) workgroups of
+  // one pixel split read the same dY / X rows, so consecutive LOGICAL ids (tile fastest, then tap, then split) are mapped
+  // to the same XCD: the 9 taps of a 3x3 layer then share one L2 instead of pulling the rows into eight.
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, rr8 = nwg & 7, xcd = orig & 7;
+  const int logical = (xcd < rr8 ? xcd * (q8 + 1) : rr8 * (q8 + 1) + (xcd - rr8) * q8) + (orig >> 3);
+  const int T_ = p.KH * p.KW, ntile = p.n_tiles * p.c_tiles;
+  const int tile = logical % ntile, tap = (logical / ntile) % T_, split = logical / (ntile * T_);
   const int n0 = (tile / p.c_tiles) * TN, c0 = (tile % p.c_tiles) * TC;
-  const int tap = blockIdx.y;
   const int dyo = tap / p.KW - p.ph, dxo = tap % p.KW - p.pw;
   const long long shift = (long long)dyo * p.W + dxo;
-  const long long p_begin = (long long)blockIdx.z * p.per_split;
+  const long long p_begin = (long long)split * p.per_split;
   const long long p_end = (p_begin + p.per_split < p.P) ? p_begin + p.per_split : p.P;
   const int nchunks = (int)((p_end - p_begin + KC - 1) / KC);
 
-  auto make_meta = [&](int chunk) {         // threads 0 .. KC-1
-    const long long q = p_begin + (long long)chunk * KC + tid;
-    int va = 0, vb = 0;
-    if (q < p_end) {
-      va = 1;
-      const int xx = (int)(q % p.W);
-      const int yy = (int)((q / p.W) % p.H);
+  auto make_meta = [&](int chunk) {         // the first wave; lanes 0 .. KC-1 hold the pixels of the chunk (32-bit pixel indices)
+    const int q = (int)p_begin + chunk * KC + lane;
+    bool va = false, vb = false;
+    if (lane < KC && q < (int)p_end) {
+      va = true;
+      const int row = q / p.W;
+      const int xx = q - row * p.W, yy = row % p.H;
       const int sy = yy + dyo, sx = xx + dxo;
-      vb = (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) ? 1 : 0;
+      vb = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
     }
-    meta[chunk & 1][0][tid] = va;
-    meta[chunk & 1][1][tid] = vb;
+    const unsigned ma = (unsigned)__ballot(va), mb = (unsigned)__ballot(vb);
+    if (lane == 0) {
+      meta[chunk & 1][0] = ma;
+      meta[chunk & 1][1] = mb;
+    }
   };
 
-  constexpr int LA = KC * TN / 256, LB = KC * TC / 256;     // elements per thread and chunk
-  float ra[LA], rb[LB];
+  // VEC: N % 4 == 0, Cin % 4 == 0, 16-byte aligned rows -> 16-byte global loads and LDS stores (4x fewer loader instructions:
+  // the loader's address arithmetic runs on the same SIMD issue port as the MFMAs)
+  constexpr int V = VEC ? 4 : 1;
+  constexpr int EA = KC * TN / V, EB = KC * TC / V;                      // vector slots of a staged tile
+  constexpr int LA = (EA + 255) / 256, LB = (EB + 255) / 256;            // loads per thread and chunk
+  typedef typename std::conditional<VEC, floatx4, float>::type vec_t;
+  vec_t ra[LA], rb[LB];
   auto fetch = [&](int chunk) {
     const long long q0 = p_begin + (long long)chunk * KC;
-    const int* mv = &meta[chunk & 1][0][0];
+    const unsigned ma = meta[chunk & 1][0], mb = meta[chunk & 1][1];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int e = tid + i * 256;
-      const int k = e / TN, col = e % TN;
+      const int k = e / (TN / V), col = (e % (TN / V)) * V;
       const int n = n0 + col;
-      ra[i] = (mv[k] && n < p.N) ? p.dy[(q0 + k) * p.ldy + n] : 0.f;
+      vec_t v = vec_t{};
+      if (e < EA && ((ma >> k) & 1u) && n < p.N) v = *reinterpret_cast<const vec_t*>(p.dy + (q0 + k) * p.ldy + n);
+      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int e = tid + i * 256;
-      const int k = e / TC, col = e % TC;
+      const int k = e / (TC / V), col = (e % (TC / V)) * V;
       const int c = c0 + col;
-      rb[i] = (mv[KC + k] && c < p.Cin) ? p.x[(q0 + k + shift) * p.ldx + c] : 0.f;
+      vec_t v = vec_t{};
+      if (e < EB && ((mb >> k) & 1u) && c < p.Cin) v = *reinterpret_cast<const vec_t*>(p.x + (q0 + k + shift) * p.ldx + c);
+      rb[i] = v;
     }
   };
+  // bias gradient = column sums of dY: the (tap 0, first column tile) workgroups add up the dY tiles they stage anyway
+  // (a thread always loads the same V columns: 256 is a multiple of TN / V)
+  const bool do_bias = p.bias_part != nullptr && tap == 0 && (tile % p.c_tiles) == 0;
+  vec_t bsum = vec_t{};
   auto stash = [&](int buf) {
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < LA; ++i) bsum += ra[i];
+    }
     float* As = lds + buf * STAGE;
     float* Bs = As + KC * SA;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int e = tid + i * 256;
-      As[(e / TN) * SA + e % TN] = ra[i];
+      if (e < EA) *reinterpret_cast<vec_t*>(As + (e / (TN / V)) * SA + (e % (TN / V)) * V) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int e = tid + i * 256;
-      Bs[(e / TC) * SB + e % TC] = rb[i];
+      if (e < EB) *reinterpret_cast<vec_t*>(Bs + (e / (TC / V)) * SB + (e % (TC / V)) * V) = rb[i];
     }
   };
 
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (nchunks > 0) {
-    if (tid < KC) {
+    if (wave == 0) {
       make_meta(0);
       if (nchunks > 1) make_meta(1);
     }
@@ -125,22 +154,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       if (ch + 1 < nchunks) fetch(ch + 1);                   // meta of chunk ch+1 was published one barrier ago
       const float* As = lds + buf * STAGE;
       const float* Bs = As + KC * SA;
+      // fragments are double buffered in registers: the LDS reads of pixel pair kp + 1 are issued before the MFMAs of pair
+      // kp (reusing one register set makes every read wait for the last MFMA of the previous group to pick up its
+      // operands, and every MFMA group wait a full LDS latency: measured 47 % MFMA-busy, 60 % of wave time in issue stalls)
+      constexpr int NKP = (KC / 2 + WK - 1) / WK;
+      float a[2][FN], b[2][FC];
+      auto frag = [&](int set, int kp) {
 #pragma unroll
-      for (int kp = wk; kp < KC / 2; kp += WK) {
-        float a[FN], b[FC];
+        for (int i = 0; i < FN; ++i) a[set][i] = As[(2 * kp + h) * SA + (wn * FN + i) * 32 + r];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) a[i] = As[(2 * kp + h) * SA + (wn * FN + i) * 32 + r];
+        for (int j = 0; j < FC; ++j) b[set][j] = Bs[(2 * kp + h) * SB + (wc * FC + j) * 32 + r];
+      };
+      frag(0, wk);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // (the first pair's reads: the groups below then hold the NEXT pair's)
 #pragma unroll
-        for (int j = 0; j < FC; ++j) b[j] = Bs[(2 * kp + h) * SB + (wc * FC + j) * 32 + r];
+      for (int q = 0; q < NKP; ++q) {
+        if (q + 1 < NKP) frag((q + 1) & 1, wk + (q + 1) * WK);
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-          for (int j = 0; j < FC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < FC; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][i], b[q & 1][j], acc[i][j], 0, 0, 0);
+        // scheduling shape of one step: the two (paired) LDS reads of the NEXT pixel pair, then this pair's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, FN * FC, 0);
       }
       if (ch + 1 < nchunks) stash(buf ^ 1);                  // the other buffer was last read before the previous barrier
-      if (ch + 2 < nchunks && tid < KC) make_meta(ch + 2);   // slot of chunk ch: its readers (fetch(ch)) are done
+      if (ch + 2 < nchunks && wave == 0) make_meta(ch + 2);  // slot of chunk ch: its readers (fetch(ch)) are done
       __syncthreads();
     }
+  }
+
+  // ---- bias partial: the 256 / (TN / V) threads that share a column group are summed through LDS
+  if (do_bias) {          // workgroup-uniform; all stage reads finished at the last barrier
+    constexpr int CG = TN / V;
+    vec_t* red2 = reinterpret_cast<vec_t*>(lds);
+    red2[tid] = bsum;
+    __syncthreads();
+    if (tid < CG) {
+      vec_t t = red2[tid];
+#pragma unroll
+      for (int j = 1; j < 256 / CG; ++j) t += red2[tid + j * CG];
+      float* dst = p.bias_part + (size_t)split * p.N + n0 + tid * V;
+      if constexpr (VEC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + tid * V + e < p.N) dst[e] = t[e];
+      } else {
+        if (n0 + tid < p.N) dst[0] = t;
+      }
+    }
+    __syncthreads();
   }
 
   // ---- sum the WK pixel-interleaved waves through LDS, then store the partial tile
@@ -175,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   }
   if (wk == 0) {
     const int T = p.KH * p.KW;
-    float* dst = p.part + ((size_t)blockIdx.z * T + tap) * p.N * p.Cin;
+    float* dst = p.part + ((size_t)split * T + tap) * p.N * p.Cin;
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -197,48 +261,77 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ part, int S, int T
   if (idx >= per * T) return;
   const int t = (int)(idx / per);
   const long long nc = idx % per;
-  double s = 0.0;
-  for (int k = 0; k < S; ++k) s += part[((size_t)k * T + t) * per + nc];
-  dw[nc * T + t] += (float)s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;     // independent chains: the loads of one trip are in flight together
+  const float* pp = part + (size_t)t * per + nc;
+  const size_t st = (size_t)T * per;
+  int k = 0;
+  for (; k + 3 < S; k += 4) {
+    s0 += pp[(size_t)k * st];
+    s1 += pp[(size_t)(k + 1) * st];
+    s2 += pp[(size_t)(k + 2) * st];
+    s3 += pp[(size_t)(k + 3) * st];
+  }
+  for (; k < S; ++k) s0 += pp[(size_t)k * st];
+  dw[nc * T + t] += (float)((s0 + s1) + (s2 + s3));
 }
 
 template <int WN, int WC, int FN, int FC>
 void launch(const WgradArgs& a, dim3 grid, hipStream_t st) {
-  FFSR_LAUNCH((conv_wgrad_kernel<WN, WC, FN, FC>), grid, dim3(256), 0, st, a);
+  const bool vec = (a.N % 4 == 0) && (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.dy)) & 15) == 0;
+  if (vec)
+    FFSR_LAUNCH((conv_wgrad_kernel<WN, WC, FN, FC, true>), grid, dim3(256), 0, st, a);
+  else
+    FFSR_LAUNCH((conv_wgrad_kernel<WN, WC, FN, FC, false>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace
 
 // x [B,H,W,ldx] (Cin channels), dy [B,H,W,ldy] (N channels): dw [N, Cin, KH, KW] += the weight gradient of the stride-1
-// convolution with zero padding (pad_h, pad_w) (a linear layer: B = H = 1, W = rows, KH = KW = 1).
-// partial: caller-owned scratch of partial_floats floats (>= KH*KW*N*Cin; more lets the pixels be split over more
+// convolution with zero padding (pad_h, pad_w) (a linear layer: B = H = 1, W = rows, KH = KW = 1); dbias [N] += column sums of
+// dy (the bias gradient; null = skip).
+// partial: caller-owned scratch of partial_floats floats (>= KH*KW*N*Cin + N; more lets the pixels be split over more
 // workgroups).
-extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial,
+extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                                    long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
                                    int pad_w, void* stream) {
   FFSR_CHECK(x && dy && dw && partial && B > 0 && H > 0 && W > 0 && Cin > 0 && N > 0 && KH > 0 && KW > 0 && ldx >= Cin && ldy >= N);
-  FFSR_CHECK(pad_h >= 0 && pad_w >= 0 && pad_h < KH && pad_w < KW);
+  FFSR_CHECK(pad_h >= 0 && pad_w >= 0 && pad_h < KH && pad_w < KW && (long long)B * H * W < (1ll << 31) - 64);
   const int T = KH * KW;
-  const long long per_tile = (long long)T * N * Cin;
+  const long long per_tile = (long long)T * N * Cin + (dbias ? N : 0);     // floats of scratch per pixel split
   FFSR_CHECK(partial_floats >= per_tile);
   WgradArgs a;
-  a.x = x, a.dy = dy, a.part = partial, a.ldx = ldx, a.ldy = ldy;
+  a.x = x, a.dy = dy, a.part = partial, a.bias_part = nullptr, a.ldx = ldx, a.ldy = ldy;
   a.B = B, a.H = H, a.W = W, a.Cin = Cin, a.N = N, a.KH = KH, a.KW = KW, a.ph = pad_h, a.pw = pad_w;
   a.P = (long long)B * H * W;
   const int tn = N <= 32 ? 32 : (N <= 64 ? 64 : 128), tc = Cin <= 32 ? 32 : (Cin <= 64 ? 64 : 128);
   a.n_tiles = (N + tn - 1) / tn, a.c_tiles = (Cin + tc - 1) / tc;
   const long long tiles = (long long)a.n_tiles * a.c_tiles * T;
-  // splits: enough workgroups to fill the chip a few times, at least 256 pixels each, bounded by the scratch
+  // splits: enough workgroups to fill the chip a few times, at least 256 pixels each, bounded by the scratch.  The MFMA pipe
+  // of a SIMD serves its resident waves one after the other, so the kernel takes as long as the CU that hosts the most
+  // workgroups: the count is chosen so that tiles x taps x splits fills whole multiples of the 256 CUs (9 taps x 64 splits =
+  // 576 workgroups = 2.25 per CU ran at 75 % of 9 x 85 = 765).
   long long S = (2048 + tiles - 1) / tiles;
   const long long max_by_px = (a.P + 255) / 256;
   if (S > max_by_px) S = max_by_px;
   if (S > partial_floats / per_tile) S = partial_floats / per_tile;
   if (S > 65535) S = 65535;
   if (S < 1) S = 1;
+  {
+    long long best = S;
+    double best_eff = 0.0;
+    for (long long c = S; c >= 1 && c >= S / 2; --c) {
+      const long long n = tiles * c;
+      const double eff = (double)n / (double)(((n + 255) / 256) * 256);
+      if (eff > best_eff + 1e-9) best_eff = eff, best = c;
+    }
+    S = best;
+  }
   a.per_split = ((a.P + S - 1) / S + KC - 1) / KC * KC;
   S = (a.P + a.per_split - 1) / a.per_split;
-  FFSR_CHECK(T <= 65535);
-  const dim3 grid((unsigned)(a.n_tiles * a.c_tiles), (unsigned)T, (unsigned)S);
+  FFSR_CHECK(tiles * S < (1ll << 31));
+  if (dbias) a.bias_part = partial + (size_t)S * T * N * Cin;
+  const dim3 grid((unsigned)(tiles * S));
   hipStream_t st = (hipStream_t)stream;
   if (tn == 32 && tc == 32) launch<1, 1, 1, 1>(a, grid, st);
   else if (tn == 32 && tc == 64) launch<1, 2, 1, 1>(a, grid, st);
@@ -249,6 +342,9 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   else if (tn == 64 && tc == 128) launch<2, 2, 1, 2>(a, grid, st);
   else if (tn == 128 && tc == 64) launch<2, 2, 2, 1>(a, grid, st);
   else launch<2, 2, 2, 2>(a, grid, st);
-  FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((per_tile + 255) / 256)), dim3(256), 0, st, partial, (int)S, T, N, Cin, dw);
+  const long long nw = (long long)T * N * Cin;
+  FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, partial, (int)S, T, N, Cin, dw);
+  if (dbias)
+    FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a.bias_part, (int)S, 1, N, 1, dbias);
   return ffsr_launch_status();
 }

@@ -27,6 +27,17 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SILU = range(6)
 GEMM_MODE = os.environ.get("FFSR_GEMM_MODE", "bf16x3")
 
 
+# Precision-budget experiment: FFSR_WEIGHT_LO=0 packs every weight with a ZERO lo plane, i.e. the split-bf16
+# kernels then evaluate a_hi*w_hi + a_lo*w_hi -- the arithmetic of a 2-term ("bf16x2") mode with bf16-rounded weights -- without
+# touching the kernels.  Measured by tools/precision_budget.py; not a default.
+WEIGHT_LO = os.environ.get("FFSR_WEIGHT_LO", "1") != "0"
+
+
+def set_weight_lo(on: bool):
+    global WEIGHT_LO
+    WEIGHT_LO = bool(on)
+
+
 BN128_MIN_N = 1 << 30   # the 128-column tile (2 waves/SIMD) measured slower on every shape: keep BN = 64
 
 
@@ -209,14 +220,15 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, stride=1, pad=
     lo = torch.zeros(Np, Kp, dtype=torch.bfloat16, device=device)
     h = w2.to(torch.bfloat16)
     hi[:N, :w2.shape[1]] = h
-    lo[:N, :w2.shape[1]] = (w2 - h.float()).to(torch.bfloat16)
+    if WEIGHT_LO:
+        lo[:N, :w2.shape[1]] = (w2 - h.float()).to(torch.bfloat16)
     # planes path: every tap padded to a multiple of 32 channels, rows padded to x768 (any column tile of 64/128/192/256)
     C32, Np3 = pad32(Cin), (N + 767) // 768 * 768
     w3 = torch.zeros(Np3, KH, KW, C32, dtype=torch.float32, device=device)
     w3[:N, :, :, :Cin] = wt
     w3 = w3.reshape(Np3, KH * KW * C32)
     ph = w3.to(torch.bfloat16)
-    pl = (w3 - ph.float()).to(torch.bfloat16)
+    pl = (w3 - ph.float()).to(torch.bfloat16) if WEIGHT_LO else torch.zeros_like(ph)
     return Conv(w2, None if b is None else b.detach().float().contiguous().to(device), N, Cp, KH, KW, stride,
                 pad, Cin, hi, lo, ph, pl, C32)
 

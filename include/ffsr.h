@@ -273,14 +273,14 @@ int ffsr_pack_conv_f32(const float* w, int N, int Cin, int KH, int KW, int trans
 /* depthwise weight [C, 1, KH, KW] -> tap-major [KH*KW, C] (ffsr_dwconv2d_f32's layout); flip = 1: input-gradient operator. */
 int ffsr_pack_dwconv_f32(const float* w, int C, int KH, int KW, int flip, float* dst, void* stream);
 
-/* Weight gradient of a stride-1 convolution / linear layer on the f32 MFMA:
- * dw [N, Cin, KH, KW] += sum_pix dy[pix, n] * x[pix + (ky - pad_h, kx - pad_w), c].  partial: scratch of partial_floats
- * floats (>= KH*KW*N*Cin; more = more pixel splits in flight).  Replaces autograd's conv2d / linear backward-weight for
+/* Weight (and bias) gradient of a stride-1 convolution / linear layer on the f32 MFMA:
+ * dw [N, Cin, KH, KW] += sum_pix dy[pix, n] * x[pix + (ky - pad_h, kx - pad_w), c];  dbias [N] += sum_pix dy[pix, n]
+ * (dbias NULL = no bias).  partial: scratch of partial_floats floats (>= KH*KW*N*Cin + N; more = more pixel splits in flight).  Replaces autograd's conv2d / linear backward-weight for
  * every nn.Conv2d / nn.Linear of the fusion net (e.g. enhanced_fusion_v2.py:569-576, large_kernel_attention.py:134-138). */
-int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial,
+int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                         long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
                         void* stream);
-/* Depthwise (groups = C) weight gradient, KH*KW <= 25: large_kernel_attention.py:58-76 (5x5, 1x21, 21x1).
+/* Depthwise (groups = C) weight gradient for the kernel shapes 5x5, 1x21, 21x1 (large_kernel_attention.py:58-76) and 3x3.
  * partial: nchunk * KH*KW * C floats. */
 int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial, int nchunk, int B, int H,
                           int W, int C, int KH, int KW, int pad_h, int pad_w, void* stream);

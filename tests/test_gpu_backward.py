@@ -118,11 +118,12 @@ def test_wgrad_large_pixel_count_is_split_deterministically():
     for _ in range(2):
         dw = torch.zeros(128, 128, 3, 3, device=DEV)
         part = torch.empty(1 << 24, device=DEV)
-        hip.call("ffsr_conv_wgrad_f32", xm.data_ptr(), 128, dm.data_ptr(), 128, dw.data_ptr(), part.data_ptr(), part.numel(), 2, 64,
-                 256, 128, 128, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
-        outs.append(dw.cpu())
-    assert torch.equal(outs[0], outs[1])
-    assert rel(outs[0], want) < 1e-4
+        db = torch.zeros(128, device=DEV)
+        hip.call("ffsr_conv_wgrad_f32", xm.data_ptr(), 128, dm.data_ptr(), 128, dw.data_ptr(), db.data_ptr(), part.data_ptr(),
+                 part.numel(), 2, 64, 256, 128, 128, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0], want) < 1e-4 and rel(outs[0][1], dy.sum((0, 2, 3))) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------- depthwise / norms

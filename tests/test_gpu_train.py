@@ -103,3 +103,30 @@ def test_cache_extract_writes_what_the_oracle_experts_produce(tmp_path):
     live = E.map_to_nchw(eng.process(lrm))
     cached = E.map_to_nchw(eng.fusion(lrm, imgs_m, feats_m))
     assert (live - cached).abs().max().item() < 1e-6
+
+
+def test_tta_cache_roundtrip_matches_on_the_fly_tta(tmp_path):
+    """SURVEY 8 f3, cached route: extract_tta writes the 8 x 3 part files of scripts/extract_test_tta_cache.py (fp16, with
+    tta_info); fuse_tta = scripts/generate_fast_submission.py's per-image loop.  The result must agree with the on-the-fly
+    Engine.process_tta up to the fp16 storage of the cached expert outputs, and generate_submission writes '{stem}x4.png'."""
+    from test_gpu_models import lr_image
+    W, E, C = mod("weights"), mod("engine"), mod("cache")
+    eng = E.Engine(W.random_weights(seed=41, small=True), DEV)
+    lr = lr_image(33, 1, 24, 40)                                              # non-square: rot90 variants swap H and W
+    stem = C.tta_stem("0901x4.png")
+    assert stem == "0901" and C.extract_tta(eng, lr, tmp_path, stem) == 8
+    assert C.extract_tta(eng, lr, tmp_path, stem, resume=True) == 0 and C.list_tta_stems(tmp_path) == ["0901"]
+    d5 = torch.load(tmp_path / "0901_t5_drct_part.pt", weights_only=True)
+    assert d5["tta_info"] == {"hflip": True, "rot": 1, "t_idx": 5} and tuple(d5["lr"].shape) == (3, 40, 24)
+    assert d5["lr"].dtype == torch.float16 and tuple(d5["outputs"]["drct"].shape) == (1, 3, 160, 96)
+    assert torch.equal(d5["lr"].float(), torch.rot90(torch.flip(lr, [3]), 1, [2, 3])[0].half().float())
+    cached = E.map_to_nchw(C.fuse_tta(eng, tmp_path, stem))
+    live = E.map_to_nchw(eng.process_tta(E.nchw_to_map(lr, DEV)))
+    assert tuple(cached.shape) == (1, 3, 96, 160) and (cached - live).abs().max().item() < 5e-3      # fp16 cache
+    one = E.map_to_nchw(C.fuse_tta(eng, tmp_path, stem, num_variants=1))
+    assert (one - E.map_to_nchw(eng.process(E.nchw_to_map(lr, DEV)))).abs().max().item() < 5e-3
+    names = C.generate_submission(eng, tmp_path, tmp_path / "res")
+    assert names == ["0901x4.png"]
+    from PIL import Image
+    with Image.open(tmp_path / "res" / "0901x4.png") as im:
+        assert im.size == (160, 96)
