@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libffsr_hip.so")
+LIB_PATH = os.environ.get("FFSR_LIB") or os.path.join(_HERE, "libffsr_hip.so")   # FFSR_LIB: A/B builds of the same library (tools/ab)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ffsr.h")
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong, "double": ctypes.c_double}
