@@ -254,6 +254,186 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   }
 }
 
+// ---- thin 3-wide layers: the three horizontal taps of a kernel row in ONE workgroup -----------------------------------------
+// With at most 32 x 32 (n, c) per wave the per-tap kernel above is not MFMA- but L2-bound: each of the 9 tap workgroups
+// stages its own copy of the dY rows and of the (shifted) X rows.  Here a workgroup owns a kernel ROW ky: the X tile is staged
+// with one pixel of halo on either side (KC + 2 rows) and serves kx = 0, 1, 2 through fragment reads at row offsets 0 / 1 / 2;
+// dY is staged once for the three taps; every wave keeps three accumulators.  What a shifted read picks up across an image
+// border (the neighbouring row's pixel) is replaced by zero at fragment time from a per-chunk, per-tap validity mask.
+// Grid = tiles x KH x splits: a third of the workgroups, a third of the staged bytes, the same MFMA work.
+// KC = pixels per staged chunk: 64 for the 32 x 32 tile (4 % faster than 16), 16 elsewhere (32 measured 15-20 % slower on the
+// 32 x 128 / 128 x 32 / 64 x 64 tiles: fewer resident workgroups)
+template <int WN, int WC, int KC>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradArgs p) {
+  typedef unsigned long long mask_t;
+  constexpr int WK = 4 / (WN * WC);
+  constexpr int TN = 32 * WN, TC = 32 * WC, KB = KC + 2;
+  constexpr int SA = TN + 32, SB = TC + 32;
+  constexpr int STAGE = KC * SA + KB * SB;
+  constexpr int RED = (WK > 1) ? WK * TN * TC : 0;
+  constexpr int LDS_FLOATS = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  __shared__ float lds[LDS_FLOATS];
+  __shared__ mask_t meta[2][4];                           // [slot][0: dY rows valid, 1 + kx: X valid for tap kx]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wk = wave % WK, wc = (wave / WK) % WC, wn = wave / (WK * WC);
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, rr8 = nwg & 7, xcd = orig & 7;
+  const int logical = (xcd < rr8 ? xcd * (q8 + 1) : rr8 * (q8 + 1) + (xcd - rr8) * q8) + (orig >> 3);
+  const int ntile = p.n_tiles * p.c_tiles;
+  const int tile = logical % ntile, ky = (logical / ntile) % p.KH, split = logical / (ntile * p.KH);
+  const int n0 = (tile / p.c_tiles) * TN, c0 = (tile % p.c_tiles) * TC;
+  const int dyo = ky - p.ph;
+  const long long shift = (long long)dyo * p.W - 1;         // staged X row j <-> flat pixel q0 + shift + j  (pad_w = 1)
+  const long long p_begin = (long long)split * p.per_split;
+  const long long p_end = (p_begin + p.per_split < p.P) ? p_begin + p.per_split : p.P;
+  const int nchunks = (int)((p_end - p_begin + KC - 1) / KC);
+
+  auto make_meta = [&](int chunk) {         // the first wave; lanes 0 .. KC-1 = the pixels of the chunk
+    const int q = (int)p_begin + chunk * KC + lane;
+    bool va = false, v0 = false, v1 = false, v2 = false;
+    if (lane < KC && q < (int)p_end) {
+      va = true;
+      const int row = q / p.W;
+      const int xx = q - row * p.W, sy = row % p.H + dyo;
+      const bool yok = sy >= 0 && sy < p.H;
+      v0 = yok && xx >= 1;
+      v1 = yok;
+      v2 = yok && xx + 1 < p.W;
+    }
+    const mask_t ma = __ballot(va), m0 = __ballot(v0), m1 = __ballot(v1), m2 = __ballot(v2);
+    if (lane == 0) {
+      meta[chunk & 1][0] = ma;
+      meta[chunk & 1][1] = m0;
+      meta[chunk & 1][2] = m1;
+      meta[chunk & 1][3] = m2;
+    }
+  };
+
+  constexpr int EA = KC * TN, EB = KB * TC;
+  constexpr int LA = (EA + 255) / 256, LB = (EB + 255) / 256;
+  float ra[LA], rb[LB];
+  mask_t mk_next[3] = {0, 0, 0};       // tap masks of the chunk being fetched (read before the barrier that lets the first
+                                            // wave overwrite this meta slot two chunks later)
+  const bool do_bias = p.bias_part != nullptr && ky == 0 && (tile % p.c_tiles) == 0;
+  float bsum = 0.f;
+  auto fetch = [&](int chunk) {
+    const long long q0 = p_begin + (long long)chunk * KC;
+    const mask_t ma = meta[chunk & 1][0];
+    mk_next[0] = meta[chunk & 1][1], mk_next[1] = meta[chunk & 1][2], mk_next[2] = meta[chunk & 1][3];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int e = tid + i * 256;
+      const int k = e / TN, n = n0 + e % TN;
+      ra[i] = (e < EA && ((ma >> k) & 1) && n < p.N) ? p.dy[(q0 + k) * p.ldy + n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int e = tid + i * 256;
+      const int j = e / TC, c = c0 + e % TC;
+      const long long g = q0 + shift + j;                    // any in-range pixel may be read: invalid taps are zeroed at fragment time
+      rb[i] = (e < EB && g >= 0 && g < p.P && c < p.Cin) ? p.x[g * p.ldx + c] : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+    float* As = lds + buf * STAGE;
+    float* Bs = As + KC * SA;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int e = tid + i * 256;
+      if (do_bias) bsum += ra[i];
+      if (e < EA) As[(e / TN) * SA + e % TN] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int e = tid + i * 256;
+      if (e < EB) Bs[(e / TC) * SB + e % TC] = rb[i];
+    }
+  };
+
+  floatx16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  if (nchunks > 0) {
+    if (wave == 0) {
+      make_meta(0);
+      if (nchunks > 1) make_meta(1);
+    }
+    __syncthreads();
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int buf = ch & 1;
+      const mask_t m0 = mk_next[0], m1 = mk_next[1], m2 = mk_next[2];   // masks of chunk ch (loaded by its fetch)
+      if (ch + 1 < nchunks) fetch(ch + 1);
+      const float* As = lds + buf * STAGE;
+      const float* Bs = As + KC * SA;
+#pragma unroll
+      for (int kp = wk; kp < KC / 2; kp += WK) {
+        const int k = 2 * kp + h;
+        const float a = As[k * SA + wn * 32 + r];
+        const float* bp = Bs + k * SB + wc * 32 + r;
+        const float b0 = ((m0 >> k) & 1) ? bp[0] : 0.f;
+        const float b1 = ((m1 >> k) & 1) ? bp[SB] : 0.f;
+        const float b2 = ((m2 >> k) & 1) ? bp[2 * SB] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+      }
+      if (ch + 1 < nchunks) stash(buf ^ 1);
+      if (ch + 2 < nchunks && wave == 0) make_meta(ch + 2);
+      __syncthreads();
+    }
+  }
+
+  if (do_bias) {          // a thread always loaded the same column tid % TN: sum the 256 / TN threads of a column
+    lds[tid] = bsum;
+    __syncthreads();
+    if (tid < TN) {
+      float t = lds[tid];
+#pragma unroll
+      for (int j = 1; j < 256 / TN; ++j) t += lds[tid + j * TN];
+      if (n0 + tid < p.N) p.bias_part[(size_t)split * p.N + n0 + tid] = t;
+    }
+    __syncthreads();
+  }
+  const int T = p.KH * 3;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    floatx16 v = acc[kx];
+    if constexpr (WK > 1) {
+      float* red = lds;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[(wk * TN + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + wc * 32 + r] = v[e];
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float s = v[e];
+#pragma unroll
+          for (int q = 1; q < WK; ++q) s += red[(q * TN + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + wc * 32 + r];
+          v[e] = s;
+        }
+      }
+      __syncthreads();
+    }
+    if (wk == 0) {
+      float* dst = p.part + ((size_t)split * T + ky * 3 + kx) * p.N * p.Cin;
+      const int c = c0 + wc * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (n < p.N && c < p.Cin) dst[(size_t)n * p.Cin + c] = v[e];
+      }
+    }
+  }
+}
+
 // dW[n, c, t] += sum_s part[s, t, n, c]
 __global__ void wgrad_finish_kernel(const float* __restrict__ part, int S, int T, int N, int Cin, float* __restrict__ dw) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,7 +486,9 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   a.P = (long long)B * H * W;
   const int tn = N <= 32 ? 32 : (N <= 64 ? 64 : 128), tc = Cin <= 32 ? 32 : (Cin <= 64 ? 64 : 128);
   a.n_tiles = (N + tn - 1) / tn, a.c_tiles = (Cin + tc - 1) / tc;
-  const long long tiles = (long long)a.n_tiles * a.c_tiles * T;
+  // thin 3-wide layers (one 32 x 32 MFMA tile per wave): the three horizontal taps share a workgroup (conv_wgrad3_kernel)
+  const bool row3 = KW == 3 && pad_w == 1 && (tn / 32) * (tc / 32) <= 4 && W >= 2;
+  const long long tiles = (long long)a.n_tiles * a.c_tiles * (row3 ? KH : T);
   // splits: enough workgroups to fill the chip a few times, at least 256 pixels each, bounded by the scratch.  The MFMA pipe
   // of a SIMD serves its resident waves one after the other, so the kernel takes as long as the CU that hosts the most
   // workgroups: the count is chosen so that tiles x taps x splits fills whole multiples of the 256 CUs (9 taps x 64 splits =
@@ -318,22 +500,35 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   if (S > 65535) S = 65535;
   if (S < 1) S = 1;
   {
+    // the SMALLEST split count that gives about 6 workgroups per CU (3 were 25 % slower on the thin tiles) and balanced: every extra split is one
+    // more partial tile for the finishing kernel to read
+    long long lo = (1500 + tiles - 1) / tiles;
+    if (lo > S) lo = S;
+    if (lo < 1) lo = 1;
     long long best = S;
     double best_eff = 0.0;
-    for (long long c = S; c >= 1 && c >= S / 2; --c) {
+    for (long long c = lo; c <= S; ++c) {
       const long long n = tiles * c;
       const double eff = (double)n / (double)(((n + 255) / 256) * 256);
       if (eff > best_eff + 1e-9) best_eff = eff, best = c;
+      if (eff >= 0.97) break;
     }
     S = best;
   }
-  a.per_split = ((a.P + S - 1) / S + KC - 1) / KC * KC;
+  a.per_split = ((a.P + S - 1) / S + 63) / 64 * 64;      // a multiple of every kernel's chunk length (16 / 32 / 64 pixels)
   S = (a.P + a.per_split - 1) / a.per_split;
   FFSR_CHECK(tiles * S < (1ll << 31));
   if (dbias) a.bias_part = partial + (size_t)S * T * N * Cin;
   const dim3 grid((unsigned)(tiles * S));
   hipStream_t st = (hipStream_t)stream;
-  if (tn == 32 && tc == 32) launch<1, 1, 1, 1>(a, grid, st);
+  if (row3) {
+    if (tn == 32 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<1, 1, 64>), grid, dim3(256), 0, st, a);
+    else if (tn == 32 && tc == 64) FFSR_LAUNCH((conv_wgrad3_kernel<1, 2, 16>), grid, dim3(256), 0, st, a);
+    else if (tn == 64 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<2, 1, 16>), grid, dim3(256), 0, st, a);
+    else if (tn == 64 && tc == 64) FFSR_LAUNCH((conv_wgrad3_kernel<2, 2, 16>), grid, dim3(256), 0, st, a);
+    else if (tn == 32 && tc == 128) FFSR_LAUNCH((conv_wgrad3_kernel<1, 4, 16>), grid, dim3(256), 0, st, a);
+    else FFSR_LAUNCH((conv_wgrad3_kernel<4, 1, 16>), grid, dim3(256), 0, st, a);
+  } else if (tn == 32 && tc == 32) launch<1, 1, 1, 1>(a, grid, st);
   else if (tn == 32 && tc == 64) launch<1, 2, 1, 1>(a, grid, st);
   else if (tn == 64 && tc == 32) launch<2, 1, 1, 1>(a, grid, st);
   else if (tn == 64 && tc == 64) launch<2, 2, 1, 1>(a, grid, st);
