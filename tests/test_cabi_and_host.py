@@ -155,3 +155,37 @@ def test_boundary_signature():
     sig = inspect.signature(team.main)
     assert list(sig.parameters) == ["model_dir", "input_path", "output_path", "device"]
     assert sig.parameters["device"].default is None
+
+
+def test_imsave_jpeg_quality_matches_cv2_default(tmp_path):
+    """cv2.imwrite's default IMWRITE_JPEG_QUALITY is 95 (the reference saves with it, io.py:119); PIL's default is 75"""
+    import io as _io
+    import numpy as np
+    from PIL import Image
+    team_io = importlib.import_module("models.team29_FreqFusionSR.io")
+    img = np.random.RandomState(0).randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    for name in ("x.jpg", "y.JPEG"):
+        team_io._imsave(img, str(tmp_path / name))
+        want = _io.BytesIO()
+        Image.fromarray(img).save(want, format="JPEG", quality=95)
+        assert (tmp_path / name).read_bytes() == want.getvalue()
+    team_io._imsave(img, str(tmp_path / "z.png"))
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "z.png")), img)
+
+
+def test_config_with_a_disabled_improvement_is_refused(tmp_path, monkeypatch):
+    """the reference builds a different network when model.fusion.improvements.* is false (io.py:186-193); this engine
+    implements the submitted architecture only and must say so instead of running it silently"""
+    import yaml
+    team_io = importlib.import_module("models.team29_FreqFusionSR.io")
+    cfg = {"model": {"fusion": {"num_experts": 4, "improvements": {"edge_enhancement": False, "cross_band_attention": True}}},
+           "dataset": {"scale": 4}}
+    path = tmp_path / "train_config.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    monkeypatch.setattr(team_io, "CONFIG_PATH", str(path))
+    with pytest.raises(ValueError, match="improvements.edge_enhancement"):
+        team_io._load_engine(str(tmp_path), "cuda")
+    cfg["model"]["fusion"] = {"fusion_dim": 64}
+    path.write_text(yaml.safe_dump(cfg))
+    with pytest.raises(ValueError, match="fusion_dim"):
+        team_io._load_engine(str(tmp_path), "cuda")
