@@ -124,6 +124,35 @@ def train_bench(args):
             "roofline": {"bound": "mfma", "achieved": tflop / (dt / args.steps), "peak": peak, "unit": "TFLOP/s",
                          "frac": tflop / (dt / args.steps) / peak, "traffic": None,
                          "note": "whole step: algorithmic 3 x forward FLOPs (SURVEY 8d) / step time, not a single kernel"}}
+    if not args.no_cpu_baseline:
+        # the same step on the host: the oracle's train-mode forward differentiated by torch autograd + torch.optim.AdamW, on a
+        # bounded sample (2 of the 32 patches, one warm-up + 2 timed steps); reported in patches/s next to config.patches_per_s
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from ffsr_oracle import fusion as ofusion
+        FT = importlib.import_module("image-super-resolution_amd.fusion_train")
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        nb = 2
+        prm = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if FT.is_parameter(k)}
+        sdo = {k: prm.get(k, v.clone().float()) for k, v in sd.items()}
+        opt = torch.optim.AdamW(list(prm.values()), lr=2e-4, weight_decay=1e-4)
+        c_imgs = {n: E.map_to_nchw(v[:nb]) for n, v in imgs.items()}
+        c_feats = {n: E.map_to_nchw(v[:nb]) for n, v in feats.items()}
+        c_hr, c_lr = E.map_to_nchw(hr[:nb]), lr[:nb]
+        cdt = 0.0
+        for i in range(3):
+            t1 = time.perf_counter()
+            opt.zero_grad()
+            out = ofusion.fusion_forward(sdo, c_lr, c_imgs, c_feats, train=True)
+            torch.nn.functional.l1_loss(out.clamp(0, 1), c_hr).backward()
+            torch.nn.utils.clip_grad_norm_(list(prm.values()), 1.0)
+            opt.step()
+            if i > 0:
+                cdt += time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": 2 * nb / cdt, "unit": "patches/s", "cores": cores, "kind": "port",
+                                "sample": f"2 timed steps on {nb} of the {B} patches after one warm-up step ({cdt:.1f} s of CPU work): "
+                                          f"oracle train-mode forward + torch autograd + clip + torch.optim.AdamW"}
+        line["gpu_over_cpu"] = line["config"]["patches_per_s"] / line["cpu_baseline"]["value"]
     print(json.dumps(line))
 
 

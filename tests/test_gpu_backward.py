@@ -460,3 +460,41 @@ def _full_step_case(mode, ofusion, otrain, train_case, T, W, FT):
     # the weights the next forward uses are the updated ones (packed operands follow the flat buffer)
     cp = tr.net.refine[2]
     assert torch.equal(cp.fwd.wgt.cpu()[:, :128], got_p["refine.4.weight"].cpu().permute(0, 2, 3, 1).reshape(128, -1)[:, :128])
+
+
+def test_training_odd_size_and_gradient_accumulation():
+    """ragged patch size (20x28 LR: non-power-of-2 DFT, reflect-padded DCT blocks, odd resampler ratios in the hierarchical and
+    Laplacian pyramids) in the exact mode against the float64 oracle; and accumulation_steps = 2 (train.py:332-345): two
+    micro-batches accumulate loss / 2 gradients, the optimiser steps once, on the second call."""
+    from ffsr_oracle import fusion as ofusion
+    from make_golden import train_case
+    T, W, FT, ops = mod("train"), mod("weights"), mod("fusion_train"), mod("ops")
+    sd = {k: v for k, v in W.fusion_state_dict(seed=9).items() if v.is_floating_point() and v.numel() > 0}
+    names = [k for k in sd if FT.is_parameter(k)]
+    batches = [train_case(81, 1, 20, 28), train_case(82, 1, 20, 28)]
+    dt = torch.float64
+    s_ = {k: (v.clone().to(dt).requires_grad_(True) if k in names else v.clone().to(dt)) for k, v in sd.items()}
+    for lr, imgs, feats, hr in batches:          # BatchNorm running statistics advance between the micro-batches, as on the device
+        sr = ofusion.fusion_forward(s_, lr.to(dt), {k: v.to(dt) for k, v in imgs.items()}, {k: v.to(dt) for k, v in feats.items()},
+                                    train=True)
+        (F.l1_loss(sr.clamp(0, 1), hr.to(dt)) / 2).backward()
+    truth = {k: s_[k].grad for k in names}
+    ops.set_gemm_mode("f32")
+    try:
+        tr = T.FusionTrainer(sd, DEV, accumulation_steps=2)
+        p0 = tr.opt.param.clone()
+        for i, (lr, imgs, feats, hr) in enumerate(batches):
+            tr.step(*_train_inputs({"lr": lr, "hr": hr, "imgs": imgs, "feats": feats}))
+            if i == 0:
+                assert torch.equal(tr.opt.param, p0) and tr.opt.step_count == 0        # no optimiser step yet
+        assert tr.opt.step_count == 1 and not torch.equal(tr.opt.param, p0)
+        got = tr.opt.views(tr.opt.grad)
+        bad = []
+        for k in names:
+            scale = max(truth[k].abs().max().item(), 1e-30)
+            e = (got[k].cpu().double() - truth[k]).abs().max().item()
+            if e > 3e-3 * scale and e > 1e-12:
+                bad.append((k, e / scale, scale))
+        assert not bad, bad
+    finally:
+        ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))

@@ -4,7 +4,7 @@ set -e
 TAG=${1:-x}
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_train -- python3 $R/bench.py --config train --steps 3 --warmup 1 > $R/gpurun_out/prof_${TAG}_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_train -- python3 $R/bench.py --config train --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_train.log 2>&1
 cd $R
 f=$(ls gpurun_out/prof_${TAG}_train/*/*_kernel_stats.csv | head -1)
 cp $f gpurun_out/prof_${TAG}_train_kernel_stats.csv
