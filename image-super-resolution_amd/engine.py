@@ -45,6 +45,8 @@ class Engine:
             self.concurrent_experts = os.environ.get("FFSR_CONCURRENT_EXPERTS", "1") != "0"
             # two "lanes" (a main stream + four expert streams each): consecutive images may be submitted to alternate
             # lanes so that the latency-bound kernels of one image fill the gaps of the other (process(..., lane=i % 2))
+            # (stream priorities measured in round 2 -- MambaIR's, DRCT's or both streams high: 374-380 ms vs 367 with equal
+            #  priorities -- so all four expert streams stay at the default priority)
             self._lanes = [(torch.cuda.Stream(self.device), [torch.cuda.Stream(self.device) for _ in range(4)])
                            for _ in range(2)]
             self._streams = self._lanes[0][1]
