@@ -7,8 +7,8 @@
 // Everything is HBM-bound elementwise / reduction work over a flat fp32 buffer (the fusion net has ~1.4 M parameters; the
 // loss runs over B x 3 x 256 x 256 pixels).  Reductions are two-stage and deterministic (fixed partial layout, no
 // atomics); the clip coefficient is derived on the device from the reduced squared norm, so the step needs no host sync.
-// The backward kernels of the fusion phases are NOT part of this file (not built yet): the gradient buffer is whatever the
-// caller filled.
+// The backward kernels of the fusion phases live in ffsr_backward.hip / ffsr_wgrad.hip; this file sees the flat gradient
+// buffer they filled.
 #include "ffsr_common.h"
 
 namespace {

@@ -1,10 +1,11 @@
-"""Optimiser side of the reference's cached-feature training step on the HIP kernels of ffsr_train.hip.
+"""The reference's cached-feature training step on the HIP kernels.
 
-Mirrors, for ONE flat fp32 parameter buffer, what ``train_epoch_cached`` (train.py:251-384) does around ``loss.backward()``:
-``sr.clamp(0, 1)`` + ``L1Loss`` + the division by ``accumulation_steps`` (:326-336), ``clip_grad_norm_`` (:347-352),
-``optimizer.step()`` of ``torch.optim.AdamW`` (:354) and ``EMAModel.update`` (:358-359, checkpoint_manager.py:349-356).
-The backward pass of the fusion network itself is NOT built yet: ``FusionOptimizer.grad`` is the flat gradient buffer a
-future backward (or a test) fills.  No CPU fallback: the calls raise without the HIP library.
+``FusionTrainer.step`` is the body of ``train_epoch_cached`` (train.py:297-359).  Around ``loss.backward()`` it works on ONE
+flat fp32 parameter buffer (``FusionOptimizer``): ``sr.clamp(0, 1)`` + ``L1Loss`` + the division by ``accumulation_steps``
+(:326-336), ``clip_grad_norm_`` (:347-352), ``optimizer.step()`` of ``torch.optim.AdamW`` (:354) and ``EMAModel.update``
+(:358-359, checkpoint_manager.py:349-356) -- kernels of ffsr_train.hip.  The train-mode forward and the backward pass
+themselves are fusion_train.FusionTrainNet on autograd.Tape (kernels of the forward library + ffsr_backward.hip /
+ffsr_wgrad.hip); they fill ``FusionOptimizer.grad``.  No CPU fallback: the calls raise without the HIP library.
 """
 from __future__ import annotations
 

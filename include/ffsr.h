@@ -236,8 +236,8 @@ int ffsr_u8_planes(const unsigned char* img, int H, int W, int crop, int y_chann
 int ffsr_psnr_ssim_u8(const unsigned char* pa, const unsigned char* pb, int P, int Hc, int Wc, double* partial,
                       int n_partial, double* out, void* stream);
 
-/* ---- optimiser side of the cached-feature training step (the backward kernels of the fusion phases are
- * not built yet).  Flat fp32 buffers, deterministic two-stage reductions; `partial` is caller-owned scratch of at least
+/* ---- loss and optimiser side of the cached-feature training step (the backward kernels of the fusion
+ * phases follow further down).  Flat fp32 buffers, deterministic two-stage reductions; `partial` is caller-owned scratch of at least
  * 1024 floats (n_partial says how many).
  *
  * loss[0] = loss_scale * mean |clamp(sr, 0, 1) - hr| over M rows x C columns; grad (may be NULL) = d loss / d sr =

@@ -1,5 +1,5 @@
 """SURVEY 8 f2, optimiser side: the HIP loss / clip / AdamW / EMA kernels against torch's own autograd, AdamW and
-clip_grad_norm_ on the CPU (oracle/ffsr_oracle/train.py).  The fusion net's backward pass is not built yet."""
+clip_grad_norm_ on the CPU (oracle/ffsr_oracle/train.py); cache formats.  The backward pass itself: tests/test_gpu_backward.py."""
 import importlib
 
 import pytest
