@@ -260,12 +260,12 @@ def main():
     # per-expert split of one step (diagnostic, stderr only)
     if rank == 0:
         by_shape = {}
-        for (e0, e1, f, shape, _), ms in zip(prof, dur_ms):
-            t = by_shape.setdefault(shape, [0, 0.0, 0.0])
-            t[0] += 1; t[1] += ms; t[2] += f
-        for shape, (n, ms, f) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('FFSR_BENCH_SHAPES', '14'))]:
+        for (e0, e1, f, shape, nbytes), ms in zip(prof, dur_ms):
+            t = by_shape.setdefault(shape, [0, 0.0, 0.0, 0.0])
+            t[0] += 1; t[1] += ms; t[2] += f; t[3] += nbytes
+        for shape, (n, ms, f, nb) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('FFSR_BENCH_SHAPES', '14'))]:
             log(f"  conv M={shape[0]:8d} N={shape[1]:4d} K={shape[2]:5d} k{shape[3]} {('f32in ', 'planes', 'strip ')[shape[4]]} x{n:4d}: "
-                f"{ms:7.1f} ms {1e3 * ms / n:7.1f} us {f / ms / 1e9:6.1f} TFLOP/s")
+                f"{ms:7.1f} ms {1e3 * ms / n:7.1f} us {f / ms / 1e9:6.1f} TFLOP/s {nb / ms / 1e9:5.2f} TB/s (algorithmic bytes)")
         lp = ops.pad_reflect(lrs[0], (h + 15) // 16 * 16, (w + 15) // 16 * 16)
         for name, fn in (("drct", eng.drct), ("grl", eng.grl), ("nafnet", eng.nafnet), ("mamba", eng.mamba)):
             torch.cuda.synchronize(device)

@@ -71,8 +71,11 @@ class CAB:
         else:
             c1 = ops.conv2d(x, self.c0, act=ACT_GELU)
             c2 = ops.conv2d(ops.widen(c1, self.c2.Cin), self.c2)
-        pooled = ops.colmean(c2)                                           # [B, C]
-        s = ops.linear(pooled, self.a1, act=ACT_RELU)                      # [B, C/r] (zero padded to x4)
-        s = s.as_strided((s.shape[0], self.a3.Cin), (s.stride(0), 1), s.storage_offset())
-        att = ops.linear(s, self.a3, act=ACT_SIGMOID)                      # [B, C]
+        if c2.shape[3] <= 1024 and self.a1.N <= 64:
+            att = ops.channel_attention(c2, self.a1, self.a3)                 # pool + FC + ReLU + FC + sigmoid, 2 launches
+        else:
+            pooled = ops.colmean(c2)                                           # [B, C]
+            s = ops.linear(pooled, self.a1, act=ACT_RELU)                      # [B, C/r] (zero padded to x4)
+            s = s.as_strided((s.shape[0], self.a3.Cin), (s.stride(0), 1), s.storage_offset())
+            att = ops.linear(s, self.a3, act=ACT_SIGMOID)                      # [B, C]
         return c2, att

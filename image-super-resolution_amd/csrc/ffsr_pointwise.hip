@@ -258,6 +258,57 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
   }
 }
 
+// RCAN channel attention tail in one workgroup per batch: finish the spatial mean from the partial column sums, then
+//   att[c] = sigmoid(W2 relu(W1 mean + b1) + b2)          (mambair_arch.py:20-38, grl mixed_attn_block.py:942-961)
+// w1 [sq, ldw1] (row j = squeeze unit j over the C channels), w2 [C, ldw2].  C <= 1024, sq <= 64.  The four launches this
+// replaces (column-sum finish, two M = 1 GEMMs on a 64 x 64 tile: 12 + 27 + 13 us of pure latency) sat on the critical path
+// of every GRL / MambaIR block.
+__global__ __launch_bounds__(1024) void channel_attention_kernel(const float* __restrict__ part, int nchunk, float inv_rows,
+                                                                 const float* __restrict__ w1, int ldw1, const float* __restrict__ b1,
+                                                                 const float* __restrict__ w2, int ldw2, const float* __restrict__ b2,
+                                                                 float* __restrict__ out, int C, int sq) {
+  __shared__ float red[16][64];
+  __shared__ float mean[1024];
+  __shared__ float hid[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cl = tid & 63, kl = tid >> 6;                       // 64 channels x 16 chunk lanes
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+      const float* pp = part + (size_t)b * nchunk * C + c;
+      int k = kl;
+      for (; k + 16 < nchunk; k += 32) {
+        s0 += pp[(size_t)k * C];
+        s1 += pp[(size_t)(k + 16) * C];
+      }
+      for (; k < nchunk; k += 16) s0 += pp[(size_t)k * C];
+    }
+    red[kl][cl] = s0 + s1;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += red[i][cl];
+      mean[c] = s * inv_rows;
+    }
+    __syncthreads();
+  }
+  // squeeze: one wave per hidden unit (16 waves)
+  for (int j = kl; j < sq; j += 16) {
+    float a = 0.f;
+    for (int c = cl; c < C; c += 64) a = fmaf(w1[(size_t)j * ldw1 + c], mean[c], a);
+    a = wave_sum(a);
+    if (cl == 0) hid[j] = fmaxf(a + (b1 ? b1[j] : 0.f), 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    float a = b2 ? b2[c] : 0.f;
+    for (int j = 0; j < sq; ++j) a = fmaf(w2[(size_t)c * ldw2 + j], hid[j], a);
+    out[(size_t)b * C + c] = 1.0f / (1.0f + expf(-a));
+  }
+}
+
 // ------------------------------------------------------------------------------------------- depthwise conv
 // weights tap-major [KH*KW, C]; stride 1; zero padding
 template <int V>
@@ -683,6 +734,17 @@ extern "C" int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part
   FFSR_CHECK(x && out && part && B > 0 && R > 0 && C > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535);
   FFSR_LAUNCH(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, out, B, C, nchunk, 1.0f / (float)R);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_channel_attention_f32(const float* x, int ldx, float* part, int nchunk, const float* w1, int ldw1,
+                                          const float* b1, const float* w2, int ldw2, const float* b2, float* out, int B, int R,
+                                          int C, int sq, void* stream) {
+  FFSR_CHECK(x && part && w1 && w2 && out && B > 0 && R > 0 && C > 0 && C <= 1024 && sq > 0 && sq <= 64 && ldx >= C &&
+             ldw1 >= C && ldw2 >= sq && nchunk > 0 && nchunk <= 65535 && B <= 65535);
+  FFSR_LAUNCH(colsum_partial_kernel, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, x, ldx, part, R, C, nchunk);
+  FFSR_LAUNCH(channel_attention_kernel, dim3(B), dim3(1024), 0, ST, part, nchunk, 1.0f / (float)R, w1, ldw1, b1, w2, ldw2, b2,
+              out, C, sq);
   return ffsr_launch_status();
 }
 

@@ -482,6 +482,17 @@ def colmean(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def channel_attention(x: torch.Tensor, a1: Conv, a3: Conv) -> torch.Tensor:
+    """[B,H,W,C] -> [B,C] = sigmoid(a3(relu(a1(spatial mean)))): the squeeze-excite tail of CAB, 2 launches."""
+    B, H, W, C = x.shape
+    n = max(1, min(256, H * W // 64))
+    part = torch.empty(B, n, C, device=x.device)
+    out = torch.empty(B, C, device=x.device)
+    hip.call("ffsr_channel_attention_f32", _ptr(x), ld(x), _ptr(part), n, _ptr(a1.wgt), a1.wgt.shape[1], _ptr(a1.bias),
+             _ptr(a3.wgt), a3.wgt.shape[1], _ptr(a3.bias), _ptr(out), B, H * W, C, a1.N, _stream())
+    return out
+
+
 @dataclass
 class DwConv:
     w: torch.Tensor           # [KH*KW, C]

@@ -111,6 +111,13 @@ int ffsr_mul_add_f32(const float* a, int lda, const float* b, int ldb, int bmode
 /* out[b, c] = mean over the R rows of batch b (nn.AdaptiveAvgPool2d(1)); part: scratch [B, nchunk, C]. */
 int ffsr_colmean_f32(const float* x, int ldx, float* out, float* part, int B, int R, int C, int nchunk, void* stream);
 
+/* RCAN channel attention of CAB in two launches: att[b, c] = sigmoid(W2 relu(W1 mean_b + b1) + b2), mean_b = spatial mean of
+ * the R rows of batch b (mambair_arch.py:20-38, grl mixed_attn_block.py:942-961: AdaptiveAvgPool2d(1), Conv2d(C, C/r, 1),
+ * ReLU, Conv2d(C/r, C, 1), Sigmoid).  w1 [sq, ldw1], w2 [C, ldw2] (nn.Conv2d 1x1 weights as matrices), C <= 1024, sq <= 64;
+ * part: scratch [B, nchunk, C]. */
+int ffsr_channel_attention_f32(const float* x, int ldx, float* part, int nchunk, const float* w1, int ldw1, const float* b1,
+                               const float* w2, int ldw2, const float* b2, float* out, int B, int R, int C, int sq, void* stream);
+
 /* Depthwise KHxKW convolution, stride 1, zero padding; w tap-major [KH*KW, C]; act fused.
  * Replaces mambair_arch.py:239-247,378 (dw3x3 + SiLU) and the LKA chain large_kernel_attention.py:92-99. */
 int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo, int B, int H,

@@ -286,3 +286,18 @@ def test_frequency_bands(ops, E, pkg, h, w):
     for i, b in enumerate(want):
         close(bands[..., i, :3].permute(0, 3, 1, 2), b, 2e-5, f"band {i}")
     assert bands[..., 3].abs().max() == 0
+
+
+@pytest.mark.parametrize("B,H,W,C,sq", [(1, 352, 512, 180, 6), (2, 17, 23, 180, 10), (3, 8, 8, 60, 3)])
+def test_channel_attention_tail(ops, E, B, H, W, C, sq):
+    """RCAN channel attention of CAB (mambair_arch.py:20-38): AdaptiveAvgPool2d(1) -> 1x1 conv -> ReLU -> 1x1 conv -> sigmoid
+    in two launches, against torch"""
+    g = torch.Generator().manual_seed(C + sq)
+    x = torch.randn(B, C, H, W, generator=g)
+    w1, b1 = torch.randn(sq, C, 1, 1, generator=g) * 0.2, torch.randn(sq, generator=g)
+    w2, b2 = torch.randn(C, sq, 1, 1, generator=g), torch.randn(C, generator=g)
+    want = torch.sigmoid(F.conv2d(F.relu(F.conv2d(x.mean((2, 3), keepdim=True), w1, b1)), w2, b2))[:, :, 0, 0]
+    a1 = ops.pack_conv(w1, b1, DEV)
+    a3 = ops.pack_conv(w2, b2, DEV, cin_pad=ops.pad4(sq))
+    got = ops.channel_attention(E.nchw_to_map(x, DEV), a1, a3).cpu()
+    assert tuple(got.shape) == (B, C) and (got - want).abs().max().item() < 2e-6
