@@ -498,3 +498,26 @@ def test_training_odd_size_and_gradient_accumulation():
         assert not bad, bad
     finally:
         ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """end-to-end sanity of the whole step: 25 AdamW steps (lr 1e-3) on one fixed batch must lower the clamped-L1 loss, the EMA
+    shadow must trail the weights, and the trained weights must load back into the inference engine's fusion net"""
+    from make_golden import train_case
+    from conftest import load_golden
+    T, F_ = mod("train"), mod("fusion")
+    sd = load_golden("fusion_full.pt")["sd"]
+    lr, imgs, feats, hr = train_case(91, 2, 32, 32)
+    inputs = _train_inputs({"lr": lr, "hr": hr, "imgs": imgs, "feats": feats})
+    tr = T.FusionTrainer(sd, DEV, lr=1e-3)
+    losses = [tr.step(*inputs).item() for _ in range(25)]
+    print("loss: first 3", [f"{v:.5f}" for v in losses[:3]], "last 3", [f"{v:.5f}" for v in losses[-3:]])
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.9 * losses[0], losses
+    p, e = tr.opt.views(), tr.opt.views(tr.opt.ema)
+    k = "refine.4.weight"
+    assert (p[k].cpu() - sd[k]).abs().max() > (e[k].cpu() - sd[k]).abs().max() > 0          # EMA (0.999) lags behind
+    # the trained state_dict (reference keys) drives the inference network
+    net = F_.FusionNet({k_: v.cpu() for k_, v in tr.state_dict().items()}, DEV)
+    lrm, _, im, ft = inputs
+    out = net(lrm, im, ft)
+    assert torch.isfinite(out).all() and 0.0 <= out.min().item() and out.max().item() <= 1.0
