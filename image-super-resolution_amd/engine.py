@@ -47,16 +47,18 @@ class Engine:
             # lanes so that the latency-bound kernels of one image fill the gaps of the other (process(..., lane=i % 2))
             # (stream priorities measured in round 2 -- MambaIR's, DRCT's or both streams high: 374-380 ms vs 367 with equal
             #  priorities -- so all four expert streams stay at the default priority)
-            self._lanes = [(torch.cuda.Stream(self.device), [torch.cuda.Stream(self.device) for _ in range(4)])
-                           for _ in range(2)]
+            self._lanes = [(torch.cuda.Stream(self.device), [torch.cuda.Stream(self.device) for _ in range(5)])
+                           for _ in range(2)]       # per lane: a main stream, four expert streams and one for the fusion's LR-only phases
             self._streams = self._lanes[0][1]
             self._graphs = {}
 
     # -------------------------------------------------------------------------------------- experts
-    def run_experts(self, lr, streams=None):
+    def run_experts(self, lr, streams=None, with_lr_phases=False):
         """lr [B,h,w,3] float map -> (imgs, feats) as io._process_image builds them (io.py:224-278).
         The four experts are independent: each runs on its own HIP stream so their launch tails and small kernels
-        overlap; the caller's stream waits for all four before the fusion starts."""
+        overlap; the caller's stream waits for all four before the fusion starts.  with_lr_phases: also run the fusion
+        network's LR-only phases (frequency bands, cross-band routing, selector gates: dozens of small, latency-bound
+        launches) on a fifth stream meanwhile -> (imgs, feats, pre)."""
         B, h, w, _ = lr.shape
         s = self.scale
         hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
@@ -75,10 +77,13 @@ class Engine:
 
         jobs = [lambda: swin_like("drct", self.drct), lambda: swin_like("mamba", self.mamba),
                 lambda: swin_like("grl", self.grl), naf]
+        pre = []
+        if with_lr_phases:
+            jobs.append(lambda: pre.extend(self.fusion.lr_phases(lr)))
         if not self.concurrent_experts:
             for job in jobs:
                 job()
-            return imgs, feats
+            return (imgs, feats, tuple(pre)) if with_lr_phases else (imgs, feats)
         main = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(main)
@@ -87,11 +92,11 @@ class Engine:
             stream.wait_event(ready)
             with torch.cuda.stream(stream):
                 job()
-        for stream in streams:
+        for stream in streams[:len(jobs)]:
             main.wait_stream(stream)
-        for t in list(imgs.values()) + list(feats.values()) + [lp]:
+        for t in list(imgs.values()) + list(feats.values()) + [lp] + list(pre):
             t.record_stream(main)
-        return imgs, feats
+        return (imgs, feats, tuple(pre)) if with_lr_phases else (imgs, feats)
 
     def process(self, lr, lane=None):
         """lr [B,h,w,3] float map in [0,1] -> SR map [B,4h,4w,3] in [0,1].
@@ -99,14 +104,14 @@ class Engine:
         (the caller's stream is only waited for at the start); the caller must ``join()`` before reading the result."""
         with torch.cuda.device(self.device):
             if lane is None:
-                imgs, feats = self.run_experts(lr)
-                return self.fusion(lr, imgs, feats)
+                imgs, feats, pre = self.run_experts(lr, with_lr_phases=True)
+                return self.fusion(lr, imgs, feats, pre=pre)
             main, streams = self._lanes[lane]
             main.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(main):
                 lr.record_stream(main)
-                imgs, feats = self.run_experts(lr, streams)
-                return self.fusion(lr, imgs, feats)
+                imgs, feats, pre = self.run_experts(lr, streams, with_lr_phases=True)
+                return self.fusion(lr, imgs, feats, pre=pre)
 
     def process_graphed(self, lr):
         """process() replayed from a HIP graph captured once per input shape (hipGraph via torch.cuda.CUDAGraph: the

@@ -272,17 +272,24 @@ class FusionNet:
         return out
 
     # ------------------------------------------------------------------------------------------ whole pipeline
-    def __call__(self, lr, imgs, feats, return_stages=False):
-        """lr [B,h,w,3]; imgs: 4 x [B,4h,4w,3]; feats: [B,h,w,180|180|64|180] -> SR [B,4h,4w,3] in [0,1]."""
-        B, h, w, _ = lr.shape
-        Hh, Wh = h * self.scale, w * self.scale
+    def lr_phases(self, lr):
+        """The part of the pipeline that needs only the LR image: phase 2 (bands), phase 3 (cross-band routing) and the
+        selector's gates of phase 6.  The engine runs it on a side stream while the four experts compute."""
         bands = self.frequency_bands(lr)
         routing = self.cross_band_routing(bands)
+        gates, diff = self.selector(routing)
+        return bands, routing, gates, diff
+
+    def __call__(self, lr, imgs, feats, return_stages=False, pre=None):
+        """lr [B,h,w,3]; imgs: 4 x [B,4h,4w,3]; feats: [B,h,w,180|180|64|180] -> SR [B,4h,4w,3] in [0,1].
+        pre: the result of lr_phases(lr) if the caller already computed it."""
+        B, h, w, _ = lr.shape
+        Hh, Wh = h * self.scale, w * self.scale
+        bands, routing, gates, diff = pre if pre is not None else self.lr_phases(lr)
         cat3 = torch.empty(B, Hh, Wh, 76, device=self.device)
         enh = cat3[..., 64:76]
         self.collaborative(feats, imgs, enh)
         hier = self.hierarchical(cat3)
-        gates, diff = self.selector(routing)
         fused = torch.empty(B, Hh, Wh, 4, device=self.device)
         ops.fusion_route(enh, hier, routing, self.fw, gates, diff, fused)
         if ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3":   # the whole 6-conv stack runs on bf16 hi/lo planes
