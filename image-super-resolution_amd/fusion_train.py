@@ -40,7 +40,6 @@ def is_parameter(key: str) -> bool:
 
 class _LKA:
     def __init__(self, P, buf, p, device):
-        C = P[p + "norm1.weight"].v.shape[0]
         self.s1, self.s2 = P[p + "scale1"], P[p + "scale2"]
         bn = lambda q: BnP(P[q + ".weight"], P[q + ".bias"], buf[q + ".running_mean"], buf[q + ".running_var"])
         self.n1, self.n2, self.lbn = bn(p + "norm1"), bn(p + "norm2"), bn(p + "lka.bn")

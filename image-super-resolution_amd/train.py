@@ -9,7 +9,7 @@ ffsr_wgrad.hip); they fill ``FusionOptimizer.grad``.  No CPU fallback: the calls
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Tuple
+from typing import Dict, Tuple
 
 import torch
 
