@@ -130,3 +130,35 @@ def test_tta_cache_roundtrip_matches_on_the_fly_tta(tmp_path):
     from PIL import Image
     with Image.open(tmp_path / "res" / "0901x4.png") as im:
         assert im.size == (160, 96)
+
+
+def test_cached_dataset_entries_drive_the_training_step(tmp_path):
+    """SURVEY 8 f2 end to end, the reference's data flow: frozen experts on the HIP engine -> 3-part cache files
+    (scripts/extract_features_balanced.py format) -> CachedSRDataset-style load + default_collate (cache.load_entry / collate)
+    -> train_epoch_cached's step (train.FusionTrainer.step) on the fusion network, with gradient accumulation over two
+    micro-batches.  Checks the plumbing: shapes, finite loss, parameters move once per accumulation window."""
+    from test_gpu_models import lr_image
+    W, E, C, T = mod("weights"), mod("engine"), mod("cache"), mod("train")
+    weights = W.random_weights(seed=43, small=True)
+    eng = E.Engine(weights, DEV)
+    g = torch.Generator().manual_seed(5)
+    for i in range(4):
+        lr = lr_image(50 + i, 1, 32, 32)
+        hr = torch.rand(3, 128, 128, generator=g)
+        outs, feats = C.extract(eng, lr)
+        C.save_entry(tmp_path, f"{i:04d}x4", lr[0], hr, outs, feats)
+    stems = C.list_stems(tmp_path)
+    assert len(stems) == 4
+    tr = T.FusionTrainer(weights["fusion"], DEV, accumulation_steps=2)
+    p0 = tr.opt.param.clone()
+    losses = []
+    for b0 in (0, 2):
+        batch = C.collate([C.load_entry(tmp_path, s) for s in stems[b0:b0 + 2]])
+        assert tuple(batch["lr"].shape) == (2, 3, 32, 32) and tuple(batch["expert_feats"]["nafnet"].shape) == (2, 64, 32, 32)
+        to_map = lambda t: E.nchw_to_map(t.float(), DEV)
+        losses.append(tr.step(to_map(batch["lr"]), to_map(batch["hr"]), {k: to_map(v) for k, v in batch["expert_imgs"].items()},
+                              {k: to_map(v) for k, v in batch["expert_feats"].items()}).item())
+        assert (tr.opt.step_count == 1) == (b0 == 2)
+    assert all(0.0 < v < 1.0 for v in losses) and not torch.equal(tr.opt.param, p0)
+    sd = tr.state_dict(ema=True)
+    assert set(sd) >= {"refine.0.weight", "cross_band.lka_block.norm1.running_mean"}
