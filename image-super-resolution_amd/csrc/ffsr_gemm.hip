@@ -450,6 +450,10 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
       return;
     }
   }
+  // wave-uniform: may whole 32-column tiles be written with 16-byte stores?
+  const bool vec_ok = ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                      (!p.res || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)) &&
+                      (!p.rvec || (reinterpret_cast<uintptr_t>(p.rvec) & 15) == 0);
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
     const int n = n0 + wcol + jn * 32 + r;
@@ -473,6 +477,38 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
           for (int e = 0; e < 16; ++e) v[e] = ffsr_act(v[e], p.act, p.slope);
       }
       const int mrow = m0 + wrow + im * 32 + 4 * h;   // + (e&3) + 8*(e>>2)
+      if (!p.shuffle && vec_ok && n0 + wcol + jn * 32 + 32 <= p.N) {
+        // 16-byte stores: the 32x32 tile is transposed through this wave's scratch (the staging LDS is idle now) so that a
+        // lane owns 8 consecutive columns of one row (the accumulator layout has one column per lane = 4-byte stores;
+        // A/B in round 2: the 340x510 step 368.6 -> 362.7 ms)
+        float* T = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = v[e] * cs;
+        const int erow = lane >> 2, ecol = (lane & 3) * 8;
+        const int nn = n0 + wcol + jn * 32 + ecol;
+        floatx4 rs0 = {p.rscale, p.rscale, p.rscale, p.rscale}, rs1 = rs0;
+        if (p.res && p.rvec) {
+          rs0 *= *reinterpret_cast<const floatx4*>(p.rvec + nn);
+          rs1 *= *reinterpret_cast<const floatx4*>(p.rvec + nn + 4);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int row = pass * 16 + erow;
+          const int m = m0 + wrow + im * 32 + row;
+          if (m >= p.M) continue;
+          const float* tp = T + row * 36 + ecol;
+          floatx4 o0 = *reinterpret_cast<const floatx4*>(tp), o1 = *reinterpret_cast<const floatx4*>(tp + 4);
+          if (p.res) {
+            const float* rp = p.res + (size_t)m * p.ldr + nn;
+            o0 += *reinterpret_cast<const floatx4*>(rp) * rs0;
+            o1 += *reinterpret_cast<const floatx4*>(rp + 4) * rs1;
+          }
+          float* op = p.out + (size_t)m * p.ldo + nn;
+          *reinterpret_cast<floatx4*>(op) = o0;
+          *reinterpret_cast<floatx4*>(op + 4) = o1;
+        }
+        continue;
+      }
       if (!p.shuffle) {
         float* op = p.out + (size_t)mrow * p.ldo + n;
         const float* rp = p.res ? p.res + (size_t)mrow * p.ldr + n : nullptr;
