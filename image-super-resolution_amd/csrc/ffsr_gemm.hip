@@ -432,9 +432,42 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
       const float ba = p.bias ? p.bias[na] : 0.f, bb = p.bias ? p.bias[na + 32] : 0.f;
       const float cs = (p.cvec ? p.cvec[no] : 1.f) * p.cscale;
       const float rs = (p.rvec ? p.rvec[no] : 1.f) * p.rscale;
+      const bool gvec = ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                        (!p.res || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)) &&
+                        (!p.rvec || (reinterpret_cast<uintptr_t>(p.rvec) & 15) == 0);
 #pragma unroll
       for (int im = 0; im < TM; ++im) {
         const int mrow = m0 + wrow + im * 32 + 4 * h;
+        if (gvec) {      // same 16-byte store path as the plain epilogue below: transpose the 32 gated columns through LDS
+          float* T = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = (acc[im][0][e] + ba) * (acc[im][1][e] + bb) * cs;
+          const int erow = lane >> 2, ecol = (lane & 3) * 8;
+          const int nn = (n0 + wcol) / 2 + ecol;
+          floatx4 rs0 = {p.rscale, p.rscale, p.rscale, p.rscale}, rs1 = rs0;
+          if (p.res && p.rvec) {
+            rs0 *= *reinterpret_cast<const floatx4*>(p.rvec + nn);
+            rs1 *= *reinterpret_cast<const floatx4*>(p.rvec + nn + 4);
+          }
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 16 + erow;
+            const int m = m0 + wrow + im * 32 + row;
+            if (m >= p.M) continue;
+            const float* tp = T + row * 36 + ecol;
+            floatx4 o0 = *reinterpret_cast<const floatx4*>(tp), o1 = *reinterpret_cast<const floatx4*>(tp + 4);
+            if (p.res) {
+              const float* rp2 = p.res + (size_t)m * p.ldr + nn;
+              o0 += *reinterpret_cast<const floatx4*>(rp2) * rs0;
+              o1 += *reinterpret_cast<const floatx4*>(rp2 + 4) * rs1;
+            }
+            float* op2 = p.out + (size_t)m * p.ldo + nn;
+            *reinterpret_cast<floatx4*>(op2) = o0;
+            *reinterpret_cast<floatx4*>(op2 + 4) = o1;
+          }
+          continue;
+        }
         float* op = p.out + (size_t)mrow * p.ldo + no;
         const float* rp = p.res ? p.res + (size_t)mrow * p.ldr + no : nullptr;
 #pragma unroll
