@@ -209,8 +209,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 // Split-bf16 ("bf16x3") variant: every fp32 operand is split on the fly into hi = bf16(x), lo = bf16(x - hi) and the
 // product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped lo*lo
 // term and the split residue bound the per-product relative error by ~3 * 2^-18 (1.1e-5) -- 3 MFMAs at 16x the f32
-// MFMA rate.  Same tiling and epilogue as the exact kernel; LDS holds bf16 hi/lo planes with 80-byte rows
-// (5 x 16 B: odd -> ds_read_b128 conflict-free).  Entry point: ffsr_conv2d_bf16x3 (the engine's default GEMM mode).
+// MFMA rate.  Same tiling as the exact kernel; LDS holds bf16 hi/lo planes in unpadded 64-byte rows with the planes
+// kernel's XOR chunk swizzle (round 1 used 80-byte rows: conflict-free for the b128 fragment reads but not for the staging
+// stores -- 33 % of its LDS cycles were bank conflicts, profiles/r02_gemm_pmc.md).  Entry point: ffsr_conv2d_bf16x3 (the engine's default GEMM mode).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int AR = BM / 32, BRW = (BN + 63) / 64;
-  constexpr int RS = 80;
+  // 64-byte rows, no padding: the 16-byte chunk c of row r lives in slot c ^ ((r >> 2) & 3) (the planes kernel's scheme):
+  // conflict-free for the 8- / 16-byte staging stores AND for the ds_read_b128 fragment reads
+  constexpr int RS = 64;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * RS];
   __shared__ int tapoff[32];
   unsigned char* const Ahi = smem;
@@ -361,14 +364,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
     for (int i = 0; i < AR; ++i) {
       uintx2 hi, lo;
       split4(a_reg[i], hi, lo);
-      const int o = (rbase + 32 * i) * RS + kofs * 2;
+      const int o = (rbase + 32 * i) * RS + ((((kofs >> 3) ^ ((rbase >> 2) & 3)) << 4) | ((kofs * 2) & 15));
       *reinterpret_cast<uintx2*>(Ahi + o) = hi;
       *reinterpret_cast<uintx2*>(Alo + o) = lo;
     }
 #pragma unroll
     for (int j = 0; j < BRW; ++j) {
       if (BN < 64 && brow >= BN) break;
-      const int o = (brow + 64 * j) * RS + bseg * 2;
+      const int o = (brow + 64 * j) * RS + (((tid & 3) ^ ((brow >> 2) & 3)) << 4);
       *reinterpret_cast<floatx4*>(Bhi + o) = bh_reg[j];
       *reinterpret_cast<floatx4*>(Blo + o) = bl_reg[j];
     }
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
     if (kt + 1 < nk) load_tiles(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int ko = 32 * ks + 16 * h;
+      const int ko = ((2 * ks + h) ^ ((r >> 2) & 3)) << 4;
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
