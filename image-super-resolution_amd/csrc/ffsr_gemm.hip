@@ -327,6 +327,9 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
   // fragments straight from L2 (fragment-shaped 32-byte loads saturate the texture-address path: 20-50 % slower).
   floatx4 a_reg[AR];
   floatx4 bh_reg[BRW], bl_reg[BRW];   // 8 bf16 each
+  // per-(batch, k) A scaling (NAFNet's SCA): workgroup-uniform test whether the whole 128-row tile lies in one batch image
+  const bool ak_uniform = HAS_AK && (m0 / p.akrows) == (min(m0 + BM, p.M) - 1) / p.akrows;
+  const size_t ak_base = HAS_AK ? (size_t)(m0 / p.akrows) * p.Ktot : 0;
   const int brow = tid >> 2, bseg = (tid & 3) * 8;  // B loader: row, first k of its 8-element segment
   auto load_tiles = [&](int kt) {
     const int k = kt * BK + kofs;
@@ -344,11 +347,17 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
       a_reg[i] = *reinterpret_cast<const floatx4*>(src);
     }
     if (HAS_AK) {
+      if (ak_uniform) {    // all rows of this tile in one batch image (always at batch 1): one scale vector per K step
+        const floatx4 sc = *reinterpret_cast<const floatx4*>(p.akscale + ak_base + (kval ? k : 0));
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const int m = min(m0 + rbase + 32 * i, p.M - 1);
-        const size_t off = (size_t)(m / p.akrows) * p.Ktot + (kval ? k : 0);
-        a_reg[i] *= *reinterpret_cast<const floatx4*>(p.akscale + off);
+        for (int i = 0; i < AR; ++i) a_reg[i] *= sc;
+      } else {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          const int m = min(m0 + rbase + 32 * i, p.M - 1);
+          const size_t off = (size_t)(m / p.akrows) * p.Ktot + (kval ? k : 0);
+          a_reg[i] *= *reinterpret_cast<const floatx4*>(p.akscale + off);
+        }
       }
     }
 #pragma unroll
