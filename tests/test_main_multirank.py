@@ -10,6 +10,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _free_port():
+    """a rendezvous port nobody is listening on right now (a fixed port collides with leftovers of an earlier run)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 WORKER = textwrap.dedent("""
     import importlib, json, os, sys
     import numpy as np, torch
@@ -58,7 +66,7 @@ def test_main_two_ranks_pick_their_gpu_and_their_images(tmp_path):
         Image.fromarray(rng.randint(0, 256, (6, 8, 3)).astype(np.uint8)).save(inp / n)
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), str(inp), str(out)],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]

@@ -6,6 +6,14 @@ import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _free_port():
+    """a rendezvous port nobody is listening on right now (a fixed port collides with leftovers of an earlier run)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 WORKER = textwrap.dedent("""
     import importlib, os, sys, torch
     sys.path.insert(0, %r)
@@ -37,7 +45,7 @@ WORKER = textwrap.dedent("""
 def test_broadcast_and_shard_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
