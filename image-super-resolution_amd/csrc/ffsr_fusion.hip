@@ -230,3 +230,146 @@ extern "C" int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float
   FFSR_LAUNCH(ssim_map_kernel, dim3(grid_for(M)), dim3(256), 0, ST, mu1, mu2, e11, e22, e12, ld, out, ldo, M);
   return ffsr_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Thin 3x3 convolution: N <= 4 output channels (the RGB / gate heads at HR resolution: conv_last of the expert tails,
+// refine.10, to_rgb.2, edge fusion.2 / edge_gate.2 / attn.2, difficulty_net.4).  On the GEMM kernels such a layer pads N to a
+// 32-column MFMA tile (and triples it for the split-bf16 products): 10 - 30x more matrix work than the layer has, at
+// 16 TFLOP/s "useful".  Here it is what it is, a streaming reduction: LPP = Cin / 4 lanes share a pixel (4 channels per lane,
+// 16-byte loads, a group's loads cover the pixel's channel row contiguously), a group walks a horizontal run of pixels (the
+// groups of a block take vertically adjacent rows, so the 3x row overlap is served by the CU's own cache) with a
+// sliding 3x3 register window (3 new loads per pixel), the weights of the lane's 4 channels live in registers, exact fp32 FMA,
+// the LPP partial sums are combined by DPP adds and lanes 0 .. N-1 of the group store one output each.
+//   out[pix, n] = res[pix, n] * rscale + act(sum_{tap, c} in[pix + tap, c] * w[n, tap, c] + bias[n]) * cscale
+// Sum over an aligned group of LPP lanes (every lane gets it): DPP adds inside a 16-lane row (quad swaps, then the half-row and
+// the row mirrored onto themselves), one LDS-crossbar shuffle for the 32-lane case.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+  if (LPP >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (LPP >= 4) v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (LPP >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if (LPP >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  if (LPP >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+template <int N, int LPP>
+__global__ __launch_bounds__(256) void conv3x3_thin_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                           const float* __restrict__ res, int ldr, int B, int H, int W, int run,
+                                                           int act, float slope, float cscale, float rscale) {
+  constexpr int CIN = 4 * LPP, GPB = 256 / LPP;              // groups (pixel runs) per block
+  const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+  // a block = GPB vertically adjacent rows x one run of columns: its groups read GPB + 2 input rows between them, at the same
+  // time, on one CU (groups of other blocks -- other XCDs, other L2s -- share only the two halo rows)
+  const int runs_per_row = (W + run - 1) / run, nyb = (H + GPB - 1) / GPB;
+  const int xr = (int)(blockIdx.x % runs_per_row);
+  const int yb = (int)((blockIdx.x / runs_per_row) % nyb), b = (int)(blockIdx.x / runs_per_row / nyb);
+  const bool live = yb * GPB + g < H;                        // (idle groups still take part in the lane exchanges)
+  const int y = min(yb * GPB + g, H - 1);
+  const int x0 = xr * run, x1 = min(W, x0 + run);
+  // rows outside the image: the row index is clamped (the loads stay unconditional) and the lane's weights of that kernel row
+  // are zero; columns outside: the column is clamped and the loaded vector multiplied by 0.  All addresses are 32-bit byte
+  // offsets from `in` (the entry point checks the map is below 4 GiB).
+  floatx4 wt[N][9];
+  unsigned roff[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = y + ky - 1;
+    const float rowm = (yy >= 0 && yy < H) ? 1.f : 0.f;
+    roff[ky] = (unsigned)(((b * H + min(max(yy, 0), H - 1)) * W) * ldi + 4 * l) * 4u;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        wt[n][ky * 3 + kx] = *reinterpret_cast<const floatx4*>(w + ((size_t)n * 9 + ky * 3 + kx) * CIN + 4 * l) * rowm;
+  }
+  const char* inb = reinterpret_cast<const char*>(in);
+  const unsigned ldb = (unsigned)ldi * 4u, cmax = (unsigned)(W - 1) * ldb;
+  auto col = [&](int ky, unsigned coff, float m) -> floatx4 {
+    return *reinterpret_cast<const floatx4*>(inb + (size_t)(roff[ky] + coff)) * m;
+  };
+  // ring of R columns x 3 rows, the loop unrolled R times so that every index is static (no register moves): at pixel x the
+  // window is ring[j], ring[j+1], ring[j+2] (columns x-1, x, x+1), columns x+2 .. x+R-3 are in flight and column x+R-2 is
+  // issued into the slot column x-2 just left.
+  constexpr int R = N == 4 ? 6 : 8;
+  floatx4 ring[R][3];
+#pragma unroll
+  for (int j = 0; j < R - 1; ++j) {
+    const int c = x0 - 1 + j;
+    const unsigned coff = (unsigned)min(max(c, 0), W - 1) * ldb;
+    const float m = (c >= 0 && c < W) ? 1.f : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) ring[j][ky] = col(ky, coff, m);
+  }
+  unsigned coff = (unsigned)min(x0 + R - 2, W - 1) * ldb;   // column x + R - 2 of the pixel x about to be computed
+  size_t pix = ((size_t)b * H + y) * W + x0;
+  const float bl = (bias && l < N) ? bias[l] : 0.f;
+  for (int xb = x0; xb < x1; xb += R) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int x = xb + j;
+      const float m = (x + R - 2 < W) ? 1.f : 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) ring[(j + R - 1) % R][ky] = col(ky, coff, m);
+      coff = min(coff + ldb, cmax);
+      float acc[N];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        floatx4 a = ring[j % R][0] * wt[n][0];
+#pragma unroll
+        for (int t = 1; t < 9; ++t) a += ring[(j + t % 3) % R][t / 3] * wt[n][t];
+        acc[n] = group_sum<LPP>((a[0] + a[1]) + (a[2] + a[3]));
+      }
+      if (live && l < N && x < x1) {
+        float v = acc[0];
+#pragma unroll
+        for (int n = 1; n < N; ++n) v = (l == n) ? acc[n] : v;
+        v = ffsr_act(v + bl, act, slope) * cscale;
+        if (res) v += res[pix * ldr + l] * rscale;
+        out[pix * ldo + l] = v;
+      }
+      ++pix;
+    }
+  }
+}
+
+template <int N>
+static int launch_thin(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo, const float* res, int ldr,
+                       int B, int H, int W, int Cin, int act, float slope, float cscale, float rscale, hipStream_t st) {
+  const int run = W >= 64 ? 32 : (W >= 16 ? 8 : W);
+  const long long runs_per_row = (W + run - 1) / run;
+#define FFSR_THIN(LPP)                                                                                                      \
+  FFSR_LAUNCH((conv3x3_thin_kernel<N, LPP>), dim3((unsigned)(runs_per_row * ((H + 256 / LPP - 1) / (256 / LPP)) * B)), dim3(256), 0, st, in, ldi, w, \
+              bias, out, ldo, res, ldr, B, H, W, run, act, slope, cscale, rscale)
+  switch (Cin) {
+    case 8: FFSR_THIN(2); break;
+    case 16: FFSR_THIN(4); break;
+    case 32: FFSR_THIN(8); break;
+    case 64: FFSR_THIN(16); break;
+    case 128: FFSR_THIN(32); break;
+    default: return FFSR_EINVAL;
+  }
+#undef FFSR_THIN
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_conv3x3_thin_f32(const float* in, int ldi, const float* wgt, const float* bias, float* out, int ldo,
+                                     const float* res, int ldr, int B, int H, int W, int Cin, int N, int act, float slope,
+                                     float cscale, float rscale, void* stream) {
+  FFSR_CHECK(in && wgt && out && B > 0 && H > 0 && W > 0 && N >= 1 && N <= 4 && ldo >= N && (!res || ldr >= N));
+  FFSR_CHECK((Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128) && ldi >= Cin && (ldi & 3) == 0 &&
+             ((uintptr_t)in & 15) == 0 && ((uintptr_t)wgt & 15) == 0);
+  FFSR_CHECK((long long)B * H * W * ldi * 4 < (1ll << 32) && N <= Cin / 4);   // 32-bit byte offsets; lanes 0 .. N-1 of a pixel's Cin/4 lanes store
+  hipStream_t st = (hipStream_t)stream;
+  switch (N) {
+    case 1: return launch_thin<1>(in, ldi, wgt, bias, out, ldo, res, ldr, B, H, W, Cin, act, slope, cscale, rscale, st);
+    case 2: return launch_thin<2>(in, ldi, wgt, bias, out, ldo, res, ldr, B, H, W, Cin, act, slope, cscale, rscale, st);
+    case 3: return launch_thin<3>(in, ldi, wgt, bias, out, ldo, res, ldr, B, H, W, Cin, act, slope, cscale, rscale, st);
+    default: return launch_thin<4>(in, ldi, wgt, bias, out, ldo, res, ldr, B, H, W, Cin, act, slope, cscale, rscale, st);
+  }
+}

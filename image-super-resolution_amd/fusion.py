@@ -294,8 +294,10 @@ class FusionNet:
         ops.fusion_route(enh, hier, routing, self.fw, gates, diff, fused)
         if ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3":   # the whole 6-conv stack runs on bf16 hi/lo planes
             r = ops.split_planes(fused[..., :3])
-            for cv in self.refine[:-1]:
-                r = ops.conv2d(r, cv, act=ACT_GELU, out_planes=True, want_f32=False)
+            thin = ops.thin3_ok(self.refine[-1], B * Hh * Wh)        # the 128 -> 3 head reads an fp32 map
+            for i, cv in enumerate(self.refine[:-1]):
+                last = thin and i == len(self.refine) - 2
+                r = ops.conv2d(r, cv, act=ACT_GELU, out_planes=None if last else True, want_f32=last)
         else:
             r = fused
             for cv in self.refine[:-1]:

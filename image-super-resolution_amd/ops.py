@@ -270,6 +270,14 @@ def planes_tile(M: int, N: int, K: int, conv3: bool = False):
 
 
 PLANES_ACTS = (ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU)
+THIN3 = os.environ.get("FFSR_THIN3", "1") != "0"   # FFSR_THIN3=0: the N <= 4 3x3 heads stay on the GEMM kernels (A/B runs)
+
+
+def thin3_ok(cv: "Conv", M: int) -> bool:
+    """3x3 / stride 1 / pad 1 with N <= 4 over an fp32 map: ffsr_conv3x3_thin_f32 (a streaming fp32 reduction) instead of a
+    32-column MFMA tile that is 7/8 padding."""
+    return (THIN3 and cv.KH == 3 and cv.KW == 3 and cv.stride == 1 and cv.pad == 1 and cv.N <= 4
+            and cv.Cin in (8, 16, 32, 64, 128) and cv.N <= cv.Cin // 4 and M >= 4096)
 PLANES_AUTO = os.environ.get("FFSR_PLANES", "1") != "0"   # FFSR_PLANES=0: every GEMM takes its fp32 input directly
 
 
@@ -292,6 +300,14 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
     else:
         oshape = (B, Ho, Wo, cv.N)
     is_planes = isinstance(x, Planes)
+    if (not is_planes and not gate and not shuffle and akscale is None and cvec is None and rvec is None and out_planes is None
+            and tile_hint == 0 and thin3_ok(cv, B * Ho * Wo) and ld(x) >= cv.Cin and B * H * W * ld(x) * 4 < 2 ** 32):
+        if out is None:
+            out = new_map(*oshape, x.device)
+        assert tuple(out.shape) == oshape and (res is None or tuple(res.shape) == oshape)
+        hip.call("ffsr_conv3x3_thin_f32", _ptr(x), ld(x), _ptr(cv.wgt), _ptr(cv.bias), _ptr(out), ld(out), _ptr(res),
+                 0 if res is None else ld(res), B, H, W, cv.Cin, cv.N, act, float(slope), float(cscale), float(rscale), _stream())
+        return out
     if gate:
         if is_planes or GEMM_MODE != "bf16x3" or shuffle or act != ACT_NONE or cv.N % 64 or B * Ho * Wo <= 64 * 24:
             raise ValueError("gate=True needs an fp32 map input, the split-bf16 mode, no activation and N % 64 == 0")

@@ -227,6 +227,16 @@ int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, co
                         const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo, int B,
                         int h, int w, int Hh, int Wh, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with N <= min(4, Cin / 4) output channels and Cin in {8, 16, 32, 64, 128} (wgt [N, 9 * Cin] tap-major
+ * fp32, the layout of ffsr_conv2d_f32): out = res * rscale + act(conv + bias) * cscale, exact fp32 FMA.  The RGB / gate heads at
+ * HR resolution -- conv_last of the expert tails (drct_arch.py:789, grl_arch.py:517, mambair_arch.py:669), NAFNet's ending
+ * (nafnet_arch.py:190), refine.10 (enhanced_fusion_v2.py:576), to_rgb.2 (hierarchical_fusion.py:124), fusion.2 / edge_gate.2 /
+ * attn.2 (edge_enhancement.py:88,177), difficulty_net.4 (enhanced_fusion_v2.py:436) -- as the streaming reduction they are
+ * instead of a 32-column MFMA tile. */
+int ffsr_conv3x3_thin_f32(const float* in, int ldi, const float* wgt, const float* bias, float* out, int ldo, const float* res,
+                          int ldr, int B, int H, int W, int Cin, int N, int act, float slope, float cscale, float rscale,
+                          void* stream);
+
 /* SSIM map from Gaussian-filtered moments (src/utils/metrics.py:129-186, calculate_ssim_torch); one channel, stride ld. */
 int ffsr_ssim_map_f32(const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12, int ld,
                       float* out, int ldo, long long M, void* stream);

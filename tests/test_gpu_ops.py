@@ -301,3 +301,33 @@ def test_channel_attention_tail(ops, E, B, H, W, C, sq):
     a3 = ops.pack_conv(w2, b2, DEV, cin_pad=ops.pad4(sq))
     got = ops.channel_attention(E.nchw_to_map(x, DEV), a1, a3).cpu()
     assert tuple(got.shape) == (B, C) and (got - want).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N,act,res", [(1, 96, 160, 64, 3, 0, False), (2, 67, 131, 128, 3, 0, True),
+                                                 (1, 70, 70, 16, 4, 1, False), (1, 64, 80, 8, 1, 4, False),
+                                                 (1, 65, 64, 32, 2, 3, True), (3, 40, 37, 8, 2, 2, False)])
+def test_thin_conv3x3_heads(ops, B, H, W, Cin, N, act, res):
+    """The N <= 4 3x3 heads at HR resolution (conv_last drct_arch.py:789, refine.10 enhanced_fusion_v2.py:576, the edge gates
+    edge_enhancement.py:88,177 ...) on ffsr_conv3x3_thin_f32: exact fp32 FMA against an fp64 torch convolution, image borders,
+    partial row blocks and ragged runs included; the dispatcher takes it for these shapes and only these."""
+    g = torch.Generator().manual_seed(Cin * 10 + N)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w, b = torch.randn(N, Cin, 3, 3, generator=g) * 0.1, torch.randn(N, generator=g)
+    r = torch.randn(B, N, H, W, generator=g) if res else None
+    f = {0: lambda t: t, 1: F.gelu, 2: F.relu, 3: lambda t: F.leaky_relu(t, 0.2), 4: torch.sigmoid}[act]
+    want = f(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if res:
+        want = want * 0.1 + r.double()
+    cv = ops.pack_conv(w, b, DEV)
+    assert ops.thin3_ok(cv, B * H * W)
+    xm = torch.empty(B, H, W, Cin, device=DEV).copy_(x.permute(0, 2, 3, 1))
+    rm = None
+    if res:
+        rm = ops.new_map(B, H, W, N, DEV)
+        rm.copy_(r.permute(0, 2, 3, 1))
+    got = ops.conv2d(xm, cv, act=act, slope=0.2 if act == 3 else 0.0, res=rm, cscale=0.1 if res else 1.0)
+    assert (got.permute(0, 3, 1, 2).double().cpu() - want).abs().max().item() < 5e-6
+    # not eligible: more output channels than the pixel has lanes, or a channel count the kernel has no instance for
+    assert not ops.thin3_ok(ops.pack_conv(torch.randn(3, 8, 3, 3), None, DEV), 1 << 20)
+    assert not ops.thin3_ok(ops.pack_conv(torch.randn(3, 48, 3, 3), None, DEV), 1 << 20)
+    assert not ops.thin3_ok(ops.pack_conv(torch.randn(8, 64, 3, 3), None, DEV), 1 << 20)
