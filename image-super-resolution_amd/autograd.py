@@ -13,6 +13,7 @@ or several micro-batches (accumulation_steps, train.py:332) need nothing extra.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -22,6 +23,7 @@ from .ops import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, _mat, _pt
 
 ACT_CLAMP01, ACT_CLAMP_MIN = 6, 7        # codes of ffsr_act_bwd_f32 only
 N_PARTIAL = 1024
+WGRAD_BF16X3 = os.environ.get("FFSR_WGRAD_BF16X3", "1") != "0"   # =0: every weight gradient on the exact f32 MFMA kernels (A/B runs)
 
 
 class Var:
@@ -242,7 +244,7 @@ class Tape:
             else:
                 gz = gy
             part = torch.empty(max((p.weight.v.numel() + p.N) * 256, 1 << 20), device=self.device)   # room for up to 256 pixel splits
-            hip.call("ffsr_conv_wgrad_f32", _ptr(xm), ops.ld(xm), _ptr(gz), ops.ld(gz), _ptr(p.weight.g),
+            hip.call("ffsr_conv_wgrad_bf16x3" if ops.GEMM_MODE == "bf16x3" and WGRAD_BF16X3 else "ffsr_conv_wgrad_f32", _ptr(xm), ops.ld(xm), _ptr(gz), ops.ld(gz), _ptr(p.weight.g),
                      None if p.bias is None else _ptr(p.bias.g), _ptr(part),
                      part.numel(), B, H, W, p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
             if x.req:

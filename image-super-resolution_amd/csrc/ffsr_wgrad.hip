@@ -434,6 +434,281 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradArgs p) {
   }
 }
 
+// ---- split-bf16 variant for the wide 3-wide layers (128 x 128 (n, c) tiles: the refine stack's 128 -> 128 convs at HR) -------------
+// The f32 MFMA above runs at 1/16 of the bf16 rate; here the products are the GEMM kernels' three split-bf16 terms
+// (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate): a third of the matrix-pipe time per pixel pair.  A bf16
+// MFMA wants 8 consecutive k (= pixels) per lane, the slow dimension of both channels-last operands: the staged tiles stay
+// [pixel][channel] images (bf16 hi and lo, 256-byte rows, 16-byte chunks XOR-swizzled by the row) and BOTH fragments come out of
+// ds_read_b64_tr_b16, gfx950's transposing LDS read (per 16 lanes: 4 rows x 16 columns, delivered column-major) -- no transpose
+// pass anywhere.  As in conv_wgrad3_kernel a workgroup owns a kernel row: the X strip (KC + 2 pixels) serves kx = 0, 1, 2
+// through reads at row offsets 0 / 1 / 2, dY is staged once.  What a shifted tap would pick up across an image border is
+// removed in the read itself: the lane that supplies that pixel's row address points at a row of zeros (the masks are
+// wave-uniform bit sets, one bit test per read).  fp32 -> hi / lo happens once per element on the way into LDS.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+typedef short wg_short4 __attribute__((ext_vector_type(4)));
+typedef short wg_short8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wg_uint2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_uint4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned wg_img_off(int row, int ch) {   // byte offset of 16-byte chunk ch (8 channels) of a row
+  return 256u * (unsigned)row + 16u * (unsigned)(ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ wg_short4 wg_tr_read(const unsigned char* base, unsigned off) {
+  typedef __attribute__((address_space(3))) wg_short4 lds_short4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(base + off));
+}
+
+template <int KC>
+__global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
+  typedef unsigned long long mask_t;
+  constexpr int TN = 128, TC = 128, KB = KC + 2, NT = 512;
+  constexpr int A_PLANE = KC * 256, B_PLANE = (KB + 1) * 256, STAGE = 2 * A_PLANE + 2 * B_PLANE;   // X planes: + one row of zeros
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+  mask_t (*meta)[4] = reinterpret_cast<mask_t (*)[4]>(wg_smem + 2 * STAGE);   // [chunk & 3][0: dY rows valid, 1 + kx: tap kx valid]
+
+  // 8 waves = 2 per SIMD: one wave's instruction stream (fragment reads, masks, the fp32 -> bf16 staging work: ~10 vector
+  // instructions per MFMA) cannot keep the matrix pipe fed by itself -- with two, one wave's vector work issues while the
+  // other's MFMA executes.  Waves as 2 (n) x 4 (c): 64 x 32 of the 128 x 128 tile each, three taps -> 6 accumulators.
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 2, wc = wave & 3;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, rr8 = nwg & 7, xcd = orig & 7;
+  const int logical = (xcd < rr8 ? xcd * (q8 + 1) : rr8 * (q8 + 1) + (xcd - rr8) * q8) + (orig >> 3);
+  const int ntile = p.n_tiles * p.c_tiles;
+  const int tile = logical % ntile, ky = (logical / ntile) % p.KH, split = logical / (ntile * p.KH);
+  const int n0 = (tile / p.c_tiles) * TN, c0 = (tile % p.c_tiles) * TC;
+  const int dyo = ky - p.ph;
+  const long long shift = (long long)dyo * p.W - 1;         // staged X row j <-> flat pixel q0 + shift + j  (pad_w = 1)
+  const long long p_begin = (long long)split * p.per_split;
+  const long long p_end = (p_begin + p.per_split < p.P) ? p_begin + p.per_split : p.P;
+  const int nchunks = (int)((p_end - p_begin + KC - 1) / KC);
+
+  auto make_meta = [&](int chunk) {         // the first wave; lanes 0 .. KC-1 = the pixels of the chunk
+    const int q = (int)p_begin + chunk * KC + lane;
+    bool va = false, v0 = false, v1 = false, v2 = false;
+    if (lane < KC && q < (int)p_end) {
+      va = true;
+      const int row = q / p.W;
+      const int xx = q - row * p.W, sy = row % p.H + dyo;
+      const bool yok = sy >= 0 && sy < p.H;
+      v0 = yok && xx >= 1;
+      v1 = yok;
+      v2 = yok && xx + 1 < p.W;
+    }
+    const mask_t ma = __ballot(va), m0 = __ballot(v0), m1 = __ballot(v1), m2 = __ballot(v2);
+    if (lane == 0) {
+      meta[chunk & 3][0] = ma;
+      meta[chunk & 3][1] = m0;
+      meta[chunk & 3][2] = m1;
+      meta[chunk & 3][3] = m2;
+    }
+  };
+
+  // staging: a thread moves float4 units (4 channels of one pixel); its channel unit u is fixed, its rows are rowt + 16 i.
+  // Loads are unconditional (a pixel outside the split / the tensor is read from a clamped address and dropped when it is
+  // written to LDS): no branch per load.
+  constexpr int RPT = NT / 32, LA = KC / RPT, LB = (KB + RPT - 1) / RPT, NP = LA + LB;
+  const int u = tid & 31, rowt = tid >> 5;
+  // (N and Cin are multiples of the 128 x 128 tile here: no channel edge)
+  const unsigned uoff_chunk = (unsigned)(u >> 1), uoff_half = 8u * (unsigned)(u & 1);
+  // Two chunks are under way besides the one being multiplied: chunk c + 1 sits in registers (loaded during the previous
+  // iteration) and is converted / written to the other LDS buffer piece by piece; as soon as a piece's registers are free the
+  // same piece of chunk c + 2 is loaded into them -- global loads are in flight all the time, a full iteration ahead of their use.
+  floatx4 ra[LA], rb[LB];
+  mask_t mk1[3] = {0, 0, 0}, ma1 = 0;      // chunk c + 1 (in registers): tap masks for its MFMA steps, row mask for its LDS image
+  mask_t mk2[3] = {0, 0, 0}, ma2 = 0;      // chunk c + 2 (being loaded)
+  long long q01 = 0, q02 = 0;
+  const bool do_bias = p.bias_part != nullptr && ky == 0 && (tile % p.c_tiles) == 0;
+  floatx4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto uniform64 = [](mask_t v) -> mask_t {   // an LDS read lands in vector registers: keep the (wave-uniform) masks in scalar ones
+    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((mask_t)hi32 << 32) | lo32;
+  };
+  auto begin2 = [&](int chunk) {            // chunk >= nchunks: past the end (valid addresses, nothing kept)
+    const bool real = chunk < nchunks;
+    const int cc = real ? chunk : nchunks - 1;
+    ma2 = real ? uniform64(meta[cc & 3][0]) : 0ull, q02 = p_begin + (long long)cc * KC;
+    mk2[0] = uniform64(meta[cc & 3][1]), mk2[1] = uniform64(meta[cc & 3][2]), mk2[2] = uniform64(meta[cc & 3][3]);
+  };
+  auto advance = [&]() { ma1 = ma2, q01 = q02, mk1[0] = mk2[0], mk1[1] = mk2[1], mk1[2] = mk2[2]; };
+  auto fetch_piece = [&](int i) {                      // of chunk "2"; pieces 0 .. LA-1: dY rows, LA .. NP-1: X strip rows
+    if (i < LA) {
+      const long long g = q02 + rowt + RPT * i;
+      ra[i] = *reinterpret_cast<const floatx4*>(p.dy + (g < p.P ? g : p.P - 1) * p.ldy + n0 + 4 * u);
+    } else if (i < NP) {
+      long long g = q02 + shift + rowt + RPT * (i - LA);      // any in-range pixel may be read: invalid taps read the row of zeros
+      g = g < 0 ? 0 : (g < p.P ? g : p.P - 1);
+      rb[i - LA] = *reinterpret_cast<const floatx4*>(p.x + g * p.ldx + c0 + 4 * u);
+    }
+  };
+  auto put = [&](unsigned char* hi_plane, unsigned char* lo_plane, int row, const floatx4& v) {
+    unsigned h0, h1, l0, l1;
+    ffsr_split2(v[0], v[1], h0, l0);
+    ffsr_split2(v[2], v[3], h1, l1);
+    const unsigned o = wg_img_off(row, (int)uoff_chunk) + uoff_half;
+    *reinterpret_cast<wg_uint2*>(hi_plane + o) = wg_uint2{h0, h1};
+    *reinterpret_cast<wg_uint2*>(lo_plane + o) = wg_uint2{l0, l1};
+  };
+  auto stash_piece = [&](int buf, int i) {             // of chunk "1": the LDS side of its fetch_piece(i)
+    unsigned char* base = wg_smem + buf * STAGE;
+    if (i < LA) {
+      const floatx4 v = ((ma1 >> (rowt + RPT * i)) & 1) ? ra[i] : zero4;
+      if (do_bias) bsum += v;
+      put(base, base + A_PLANE, rowt + RPT * i, v);
+    } else if (i < NP) {
+      const int j = rowt + RPT * (i - LA);
+      const long long g = q01 + shift + j;
+      if (j < KB) put(base + 2 * A_PLANE, base + 2 * A_PLANE + B_PLANE, j, (g >= 0 && g < p.P) ? rb[i - LA] : zero4);
+    }
+  };
+
+  floatx16 acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][i][e] = 0.f;
+
+  // transposing-read geometry of this lane: group gq of 16 lanes takes columns 16 (gq & 1) .. + 15 of a 32-column fragment and
+  // pixels 8 (gq >> 1) .. + 7 of the 16-pixel step; lane 4 q + pp of the group supplies row q, columns 4 pp .. 4 pp + 3.
+  // The swizzle of a row depends on (row & 3) and ((row >> 2) & 3) only, both unchanged by + 16 s: every read of the chunk is one
+  // of these per-lane byte offsets + 4096 s as an immediate.
+  const int gq = (lane >> 4) & 3, li = lane & 15, rq = li >> 2, pp = li & 3;
+  const int krow = 8 * (gq >> 1) + rq;
+  const unsigned half8 = 8u * (unsigned)(pp & 1);
+  const int chA = (wn * 64 + 16 * (gq & 1)) / 8 + (pp >> 1), chB = (wc * 32 + 16 * (gq & 1)) / 8 + (pp >> 1);
+  unsigned offA[2][2], offB[3][2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) offA[fn][rr] = wg_img_off(krow + 4 * rr, chA + 4 * fn) + half8;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) offB[kx][rr] = wg_img_off(krow + kx + 4 * rr, chB) + half8;
+  }
+  auto frag = [&](const unsigned char* plane, const unsigned (&off)[2]) -> wg_bf16x8 {
+    const wg_short4 v0 = wg_tr_read(plane, off[0]);
+    const wg_short4 v1 = wg_tr_read(plane, off[1]);
+    const wg_short8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(wg_bf16x8, v);
+  };
+  // A tap that must not see pixel k (image border, rows outside the image, end of the split) reads the X row it would pair with
+  // pixel k from the plane's row of zeros instead: a transposing read takes one row address per lane, so the mask costs three
+  // vector instructions per read pair (bit of the lane's row -> offset select) and no fragment copies.
+  const unsigned zoff = 256u * KB + 8u * (unsigned)(lane & 31);
+  unsigned dB[3][2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) dB[kx][rr] = offB[kx][rr] - zoff;
+
+  if (nchunks > 0) {
+    if (tid < 256)           // the rows of zeros: 2 buffers x 2 planes x 64 dwords
+      *reinterpret_cast<unsigned*>(wg_smem + (tid >> 7) * STAGE + 2 * A_PLANE + ((tid >> 6) & 1) * B_PLANE + 256 * KB + 4 * (tid & 63)) = 0u;
+    if (wave == 0) {
+      make_meta(0);
+      if (nchunks > 1) make_meta(1);
+      if (nchunks > 2) make_meta(2);
+    }
+    __syncthreads();
+    begin2(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) fetch_piece(i);
+    advance();
+    begin2(1);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {      // chunk 0 into LDS buffer 0, chunk 1 on its way into the registers
+      stash_piece(0, i);
+      fetch_piece(i);
+    }
+    mask_t mk0[3] = {mk1[0], mk1[1], mk1[2]};   // tap masks of the chunk about to be multiplied
+    advance();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int buf = ch & 1;
+      const mask_t mk[3] = {mk0[0], mk0[1], mk0[2]};   // tap masks of chunk ch (wave-uniform, in scalar registers)
+      // Side work of the chunk, dealt over its (step, tap) slots: piece by piece, chunk ch + 1 goes from the registers to the other
+      // LDS buffer (its readers finished before the last barrier) and chunk ch + 2 is loaded in its place.  Past the last chunk
+      // the loads repeat the last rows and are dropped: no branch.
+      begin2(ch + 2);
+      constexpr int SLOTS = 3 * (KC / 16), PPER = (NP + SLOTS - 1) / SLOTS;
+      const unsigned char* Ahi = wg_smem + buf * STAGE;
+      const unsigned char* Alo = Ahi + A_PLANE;
+      const unsigned char* Bhi = Ahi + 2 * A_PLANE;
+      const unsigned char* Blo = Bhi + B_PLANE;
+      static_for<0, KC / 16>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value;
+        wg_bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) {
+          ah[fn] = frag(Ahi + 4096 * s, offA[fn]);
+          al[fn] = frag(Alo + 4096 * s, offA[fn]);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int slot = 3 * s + kx;
+          unsigned ob[2];
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {      // bit 16 s + 4 rr + krow of the tap's mask: the pixel of the row this lane addresses
+            const unsigned m = (unsigned)(mk[kx] >> (16 * s + 4 * rr));
+            ob[rr] = zoff + ((0u - ((m >> krow) & 1u)) & (dB[kx][rr] + 4096u * s));
+          }
+          const wg_bf16x8 bh = frag(Bhi, ob), bl = frag(Blo, ob);
+#pragma unroll
+          for (int fn = 0; fn < 2; ++fn) {
+            acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fn], bh, acc[kx][fn], 0, 0, 0);
+            acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bl, acc[kx][fn], 0, 0, 0);
+            acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bh, acc[kx][fn], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < PPER; ++i) {
+            stash_piece(buf ^ 1, slot * PPER + i);
+            fetch_piece(slot * PPER + i);
+          }
+        }
+      });
+      mk0[0] = mk1[0], mk0[1] = mk1[1], mk0[2] = mk1[2];
+      advance();
+      if (ch + 3 < nchunks && wave == 0) make_meta(ch + 3);   // slot of chunk ch - 1, last read when chunk ch - 1 was "2" (three iterations ago)
+      __syncthreads();
+    }
+  }
+
+  if (do_bias) {          // a thread always loaded the same 4 columns 4 u .. 4 u + 3: sum the 16 threads of a column unit
+    float* red = reinterpret_cast<float*>(wg_smem);
+    __syncthreads();
+    *reinterpret_cast<floatx4*>(red + rowt * TN + 4 * u) = bsum;
+    __syncthreads();
+    if (tid < TN) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) t += red[j * TN + tid];
+      p.bias_part[(size_t)split * p.N + n0 + tid] = t;
+    }
+  }
+  const int T = p.KH * 3, r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    float* dst = p.part + ((size_t)split * T + ky * 3 + kx) * p.N * p.Cin;
+    const int c = c0 + wc * 32 + r;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * 64 + fn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        dst[(size_t)n * p.Cin + c] = acc[kx][fn][e];
+      }
+  }
+}
+
 // dW[n, c, t] += sum_s part[s, t, n, c]
 __global__ void wgrad_finish_kernel(const float* __restrict__ part, int S, int T, int N, int Cin, float* __restrict__ dw) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,9 +747,9 @@ void launch(const WgradArgs& a, dim3 grid, hipStream_t st) {
 // dy (the bias gradient; null = skip).
 // partial: caller-owned scratch of partial_floats floats (>= KH*KW*N*Cin + N; more lets the pixels be split over more
 // workgroups).
-extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
-                                   long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
-                                   int pad_w, void* stream) {
+static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
+                      long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
+                      bool split_bf16, void* stream) {
   FFSR_CHECK(x && dy && dw && partial && B > 0 && H > 0 && W > 0 && Cin > 0 && N > 0 && KH > 0 && KW > 0 && ldx >= Cin && ldy >= N);
   FFSR_CHECK(pad_h >= 0 && pad_w >= 0 && pad_h < KH && pad_w < KW && (long long)B * H * W < (1ll << 31) - 64);
   const int T = KH * KW;
@@ -488,7 +763,10 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   a.n_tiles = (N + tn - 1) / tn, a.c_tiles = (Cin + tc - 1) / tc;
   // thin 3-wide layers (one 32 x 32 MFMA tile per wave): the three horizontal taps share a workgroup (conv_wgrad3_kernel)
   const bool row3 = KW == 3 && pad_w == 1 && (tn / 32) * (tc / 32) <= 4 && W >= 2;
-  const long long tiles = (long long)a.n_tiles * a.c_tiles * (row3 ? KH : T);
+  // wide 3-wide layers in split-bf16 mode: the transposing-read bf16 kernel (float4 staging: 4-channel units, 16-byte rows)
+  const bool wide3 = split_bf16 && KW == 3 && pad_w == 1 && W >= 2 && (N % 128 == 0) && (Cin % 128 == 0) &&
+                     (ldx % 4 == 0) && (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+  const long long tiles = (long long)a.n_tiles * a.c_tiles * ((row3 || wide3) ? KH : T);
   // splits: enough workgroups to fill the chip a few times, at least 256 pixels each, bounded by the scratch.  The MFMA pipe
   // of a SIMD serves its resident waves one after the other, so the kernel takes as long as the CU that hosts the most
   // workgroups: the count is chosen so that tiles x taps x splits fills whole multiples of the 256 CUs (9 taps x 64 splits =
@@ -502,7 +780,7 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   {
     // the SMALLEST split count that gives about 6 workgroups per CU (3 were 25 % slower on the thin tiles) and balanced: every extra split is one
     // more partial tile for the finishing kernel to read
-    long long lo = (1500 + tiles - 1) / tiles;
+    long long lo = wide3 ? 512 / tiles : (1500 + tiles - 1) / tiles;   // (the wide bf16 kernel: one workgroup per CU at a time)
     if (lo > S) lo = S;
     if (lo < 1) lo = 1;
     long long best = S;
@@ -521,7 +799,17 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   if (dbias) a.bias_part = partial + (size_t)S * T * N * Cin;
   const dim3 grid((unsigned)(tiles * S));
   hipStream_t st = (hipStream_t)stream;
-  if (row3) {
+  if (wide3) {
+    constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return FFSR_ELAUNCH;
+      attr_set = true;
+    }
+    FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW>), grid, dim3(512), LDS, st, a);
+  } else if (row3) {
     if (tn == 32 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<1, 1, 64>), grid, dim3(256), 0, st, a);
     else if (tn == 32 && tc == 64) FFSR_LAUNCH((conv_wgrad3_kernel<1, 2, 16>), grid, dim3(256), 0, st, a);
     else if (tn == 64 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<2, 1, 16>), grid, dim3(256), 0, st, a);
@@ -542,4 +830,18 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
   if (dbias)
     FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a.bias_part, (int)S, 1, N, 1, dbias);
   return ffsr_launch_status();
+}
+
+extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
+                                   long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
+                                   int pad_w, void* stream) {
+  return wgrad_impl(x, ldx, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, KH, KW, pad_h, pad_w, false, stream);
+}
+
+// The same contract with split-bf16 products (hi*hi + hi*lo + lo*hi, fp32 accumulate: the arithmetic of ffsr_conv2d_bf16x3) where
+// a kernel for the shape exists (3-wide layers with more than 64 input and output channels); other shapes take the exact fp32 path.
+extern "C" int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
+                                      long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
+                                      int pad_w, void* stream) {
+  return wgrad_impl(x, ldx, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, KH, KW, pad_h, pad_w, true, stream);
 }

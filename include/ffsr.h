@@ -297,6 +297,13 @@ int ffsr_pack_dwconv_f32(const float* w, int C, int KH, int KW, int flip, float*
 int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                         long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
                         void* stream);
+/* The same contract with split-bf16 products (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate: the arithmetic of
+ * ffsr_conv2d_bf16x3) where a kernel for the shape exists -- 3-wide layers with more than 64 input and output channels, i.e.
+ * the refine stack's 128 -> 128 convolutions at HR (enhanced_fusion_v2.py:569-576), both operands read through gfx950's
+ * transposing LDS read; every other shape runs ffsr_conv_wgrad_f32's exact fp32 kernels. */
+int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
+                           long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
+                           void* stream);
 /* Depthwise (groups = C) weight gradient for the kernel shapes 5x5, 1x21, 21x1 (large_kernel_attention.py:58-76) and 3x3.
  * partial: nchunk * KH*KW * C floats. */
 int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial, int nchunk, int B, int H,

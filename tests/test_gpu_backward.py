@@ -126,6 +126,28 @@ def test_wgrad_large_pixel_count_is_split_deterministically():
     assert rel(outs[0][0], want) < 1e-4 and rel(outs[0][1], dy.sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 64, 256, 128, 128), (1, 37, 53, 128, 128), (3, 9, 7, 132, 200), (1, 20, 64, 256, 72)])
+def test_wgrad_split_bf16_wide_layers(B, H, W, Cin, N):
+    """ffsr_conv_wgrad_bf16x3: the 3-wide layers with more than 64 channels on either side take the transposing-read bf16 kernel
+    (three split products), everything about the contract unchanged: image borders (every row / column position of the taps),
+    ragged last chunk and split, channel counts that are not multiples of the 128 x 128 tile, the bias gradient, run-to-run
+    determinism.  Truth = fp64 autograd; the error of three-term split-bf16 products is ~1e-5 relative."""
+    hip = mod("hip")
+    g = gen(B * 1000 + W)
+    x, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, N, H, W, generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (N, Cin, 3, 3), dy.double(), padding=1)
+    xm, dm = to_map(x), to_map(dy)
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(N, Cin, 3, 3, device=DEV)
+        part = torch.empty(1 << 24, device=DEV)
+        db = torch.zeros(N, device=DEV)
+        hip.call("ffsr_conv_wgrad_bf16x3", xm.data_ptr(), xm.stride(2), dm.data_ptr(), dm.stride(2), dw.data_ptr(), db.data_ptr(),
+                 part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0].double(), want) < 3e-5 and rel(outs[0][1].double(), dy.double().sum((0, 2, 3))) < 1e-5
+
 # ---------------------------------------------------------------------------------------------- depthwise / norms
 @pytest.mark.parametrize("C,kh,kw,ph,pw_", [(64, 5, 5, 2, 2), (128, 1, 21, 0, 10), (64, 21, 1, 10, 0)])
 def test_dwconv_backward(C, kh, kw, ph, pw_):

@@ -1,0 +1,33 @@
+"""Weight gradient of the refine stack's 128 -> 128 3x3 convolution at config 5's size (32 x 256 x 256 pixels):
+ffsr_conv_wgrad_f32 (f32 MFMA) against ffsr_conv_wgrad_bf16x3 (transposing-read bf16 kernel), time and error vs fp64 on a slice."""
+import importlib
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, "/root/repo")
+hip = importlib.import_module("image-super-resolution_amd.hip")
+dev = "cuda"
+torch.manual_seed(0)
+for (B, H, W, Cin, N) in [(32, 256, 256, 128, 128), (32, 64, 64, 128, 128), (8, 256, 256, 128, 128)]:
+    x = torch.randn(B, H, W, Cin, device=dev)
+    dy = torch.randn(B, H, W, N, device=dev)
+    part = torch.empty(1 << 26, device=dev)
+    res = {}
+    for name in ("ffsr_conv_wgrad_f32", "ffsr_conv_wgrad_bf16x3"):
+        def run():
+            dw = torch.zeros(N, Cin, 3, 3, device=dev)
+            hip.call(name, x.data_ptr(), Cin, dy.data_ptr(), N, dw.data_ptr(), None, part.data_ptr(), part.numel(), B, H, W, Cin, N,
+                     3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
+            return dw
+        res[name] = run()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        us = (time.time() - t0) / 5 * 1e6
+        print(f"{name} B{B} {H}x{W} {Cin}->{N}: {us:.0f} us = {2.0 * B * H * W * Cin * N * 9 / us / 1e6:.1f} TFLOP/s", flush=True)
+    a, b = res["ffsr_conv_wgrad_f32"], res["ffsr_conv_wgrad_bf16x3"]
+    print("  max rel diff bf16x3 vs f32:", ((a - b).abs().max() / a.abs().max()).item(), flush=True)
