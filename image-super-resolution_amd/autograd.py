@@ -71,10 +71,14 @@ class ConvP:
 
 def _alloc_conv(N, Cin_true, Cp, KH, KW, pad, device, bias) -> ops.Conv:
     K = KH * KW * Cp
-    Np, Kp = (N + 127) // 128 * 128, (K + 31) // 32 * 32
-    return ops.Conv(torch.empty(N, K, device=device), bias, N, Cp, KH, KW, 1, pad, Cin_true,
-                    torch.empty(Np, Kp, dtype=torch.bfloat16, device=device),
-                    torch.empty(Np, Kp, dtype=torch.bfloat16, device=device))
+    # with Cin a multiple of 32 the split-bf16 planes [rows, taps * Cp] are also the planes kernels' weight layout (every tap
+    # padded to 32 channels): rows padded to x768 (any column tile) and the same buffers serve ffsr_conv2d_planes
+    planes_ok = Cin_true % 32 == 0 and Cp == Cin_true and KH * KW > 1
+    Np, Kp = (N + 767) // 768 * 768 if planes_ok else (N + 127) // 128 * 128, (K + 31) // 32 * 32
+    hi = torch.empty(Np, Kp, dtype=torch.bfloat16, device=device)
+    lo = torch.empty(Np, Kp, dtype=torch.bfloat16, device=device)
+    return ops.Conv(torch.empty(N, K, device=device), bias, N, Cp, KH, KW, 1, pad, Cin_true, hi, lo,
+                    hi if planes_ok else None, lo if planes_ok else None, Cp if planes_ok else 0)
 
 
 class DwP:
@@ -103,9 +107,12 @@ class BnP:
         self.calls = 0                      # num_batches_tracked
 
 
-def conv_tile(M: int, N: int, taps: int) -> int:
+def conv_tile(M: int, N: int, taps: int, cin: int = 0) -> int:
     """explicit tile_hint of ops.conv2d for fp32-map inputs: the split-bf16 kernel where the default mode would take it,
-    else the exact f32 kernel (also FFSR_GEMM_MODE=f32)"""
+    else the exact f32 kernel (also FFSR_GEMM_MODE=f32).  0 = ops.conv2d's own choice: for the wide k x k layers at HR (the refine
+    stack, forward and input gradient) that is one split pass + the planes tap-strip kernel (2.2 vs 2.8 ms per layer at config 5)."""
+    if ops.GEMM_MODE == "bf16x3" and ops.PLANES_AUTO and taps > 1 and cin >= 32 and cin % 32 == 0 and N > 64 and M >= 16384:
+        return 0
     if ops.GEMM_MODE == "bf16x3" and M > 64 * 24 and taps <= 32:
         return 32 if N <= 32 else 64
     if N <= 32:
@@ -221,7 +228,7 @@ class Tape:
         xm = ops.as_map(xv) if is2d else xv
         B, H, W, _ = xm.shape
         M = B * H * W
-        hint = conv_tile(M, p.N, p.KH * p.KW)
+        hint = conv_tile(M, p.N, p.KH * p.KW, p.Cin)
         fused = act if act in (ACT_RELU, ACT_LRELU, ACT_SIGMOID) else ACT_NONE
         om = None if out is None else (ops.as_map(out) if out.dim() == 2 else out)
         if act == ACT_GELU:
@@ -248,7 +255,7 @@ class Tape:
                      None if p.bias is None else _ptr(p.bias.g), _ptr(part),
                      part.numel(), B, H, W, p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
             if x.req:
-                gx = ops.conv2d(ops.widen(gz, p.bwd.Cin), p.bwd, tile_hint=conv_tile(M, p.Cin, p.KH * p.KW))
+                gx = ops.conv2d(ops.widen(gz, p.bwd.Cin), p.bwd, tile_hint=conv_tile(M, p.Cin, p.KH * p.KW, p.N))
                 self.acc(x, _unmap(gx) if is2d else gx)
         self._rec(bw)
         return y

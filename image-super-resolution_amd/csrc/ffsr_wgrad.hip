@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradArgs p) {
   }
 }
 
-// ---- split-bf16 variant for the wide 3-wide layers (128 x 128 (n, c) tiles: the refine stack's 128 -> 128 convs at HR) -------------
+// ---- split-bf16 variant for the wide 3-wide layers (N, Cin multiples of 128: the refine stack's 128 -> 128 convs at HR) ----------
 // The f32 MFMA above runs at 1/16 of the bf16 rate; here the products are the GEMM kernels' three split-bf16 terms
 // (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate): a third of the matrix-pipe time per pixel pair.  A bf16
 // MFMA wants 8 consecutive k (= pixels) per lane, the slow dimension of both channels-last operands: the staged tiles stay
@@ -444,6 +444,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradArgs p) {
 // through reads at row offsets 0 / 1 / 2, dY is staged once.  What a shifted tap would pick up across an image border is
 // removed in the read itself: the lane that supplies that pixel's row address points at a row of zeros (the masks are
 // wave-uniform bit sets, one bit test per read).  fp32 -> hi / lo happens once per element on the way into LDS.
+// Measured on 32 x 256 x 256 pixels, 128 -> 128 (tools/wgrad_bench.py; f32 MFMA kernel: 5.7 ms): MFMAs + dY fragment reads only
+// 1.06 ms (the matrix pipe's own time for 3 x 618 GFLOP), + X fragment reads 1.27 ms, the staging work alone (loads, split,
+// LDS writes, no MFMA) 0.93 ms, everything 1.78 ms = 348 TFLOP/s: on a SIMD the vector work and the MFMAs add up rather than
+// overlap, however finely they are interleaved (sched_group_barrier shapes, one or two waves per SIMD: +-3 %).  What helped:
+// two waves per SIMD with the border masks moved into the read addresses (2.03 -> 1.92), global loads kept in flight a whole
+// iteration ahead (-> 1.78).  The remaining step is the one the forward GEMMs took: operands that arrive as bf16 planes
+// (LDS-DMA, no vector work in the loop).
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -839,7 +846,7 @@ extern "C" int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
 }
 
 // The same contract with split-bf16 products (hi*hi + hi*lo + lo*hi, fp32 accumulate: the arithmetic of ffsr_conv2d_bf16x3) where
-// a kernel for the shape exists (3-wide layers with more than 64 input and output channels); other shapes take the exact fp32 path.
+// a kernel for the shape exists (3-wide layers with N and Cin multiples of 128); other shapes take the exact fp32 path.
 extern "C" int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                                       long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
                                       int pad_w, void* stream) {

@@ -298,8 +298,8 @@ int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float
                         long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
                         void* stream);
 /* The same contract with split-bf16 products (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate: the arithmetic of
- * ffsr_conv2d_bf16x3) where a kernel for the shape exists -- 3-wide layers with more than 64 input and output channels, i.e.
- * the refine stack's 128 -> 128 convolutions at HR (enhanced_fusion_v2.py:569-576), both operands read through gfx950's
+ * ffsr_conv2d_bf16x3) where a kernel for the shape exists -- 3-wide layers (KW = 3, pad_w = 1) with N and Cin multiples of 128,
+ * i.e. the refine stack's 128 -> 128 convolutions at HR (enhanced_fusion_v2.py:569-576), both operands read through gfx950's
  * transposing LDS read; every other shape runs ffsr_conv_wgrad_f32's exact fp32 kernels. */
 int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                            long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,

@@ -126,12 +126,14 @@ def test_wgrad_large_pixel_count_is_split_deterministically():
     assert rel(outs[0][0], want) < 1e-4 and rel(outs[0][1], dy.sum((0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 64, 256, 128, 128), (1, 37, 53, 128, 128), (3, 9, 7, 132, 200), (1, 20, 64, 256, 72)])
+@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 64, 256, 128, 128), (1, 37, 53, 128, 128), (1, 20, 64, 256, 128), (2, 5, 300, 128, 256),
+                                         (3, 9, 7, 132, 200)])
 def test_wgrad_split_bf16_wide_layers(B, H, W, Cin, N):
-    """ffsr_conv_wgrad_bf16x3: the 3-wide layers with more than 64 channels on either side take the transposing-read bf16 kernel
-    (three split products), everything about the contract unchanged: image borders (every row / column position of the taps),
-    ragged last chunk and split, channel counts that are not multiples of the 128 x 128 tile, the bias gradient, run-to-run
-    determinism.  Truth = fp64 autograd; the error of three-term split-bf16 products is ~1e-5 relative."""
+    """ffsr_conv_wgrad_bf16x3: 3-wide layers whose channel counts are multiples of the 128 x 128 tile take the transposing-read
+    bf16 kernel (three split products), everything about the contract unchanged: image borders (every row / column position of
+    the taps), images narrower / wider than a 64-pixel chunk, ragged last chunk and split, several tiles, the bias gradient,
+    run-to-run determinism; the last case (132 -> 200) is a shape without such a kernel: same entry point, exact fp32 path.
+    Truth = fp64 autograd; the error of three-term split-bf16 products is ~1e-5 relative."""
     hip = mod("hip")
     g = gen(B * 1000 + W)
     x, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, N, H, W, generator=g)
@@ -354,7 +356,11 @@ def test_pack_conv_matches_load_time_packing():
         ref = ops.pack_conv(w, None, DEV, cin_pad=cin_pad)
         cp = A.ConvP(param(w), None, DEV, cin_pad=cin_pad)
         cp.repack()
-        assert torch.equal(cp.fwd.wgt, ref.wgt) and torch.equal(cp.fwd.whi, ref.whi) and torch.equal(cp.fwd.wlo, ref.wlo)
+        rows = ref.whi.shape[0]
+        assert torch.equal(cp.fwd.wgt, ref.wgt) and torch.equal(cp.fwd.whi[:rows], ref.whi) and torch.equal(cp.fwd.wlo[:rows], ref.wlo)
+        assert cp.fwd.whi[rows:].float().abs().max().item() == 0 if cp.fwd.whi.shape[0] > rows else True
+        if cp.fwd.phi is not None:      # Cin % 32 == 0: the same buffers are the planes kernels' weight operand
+            assert cp.fwd.Cp32 == ref.Cp32 and torch.equal(cp.fwd.phi, ref.phi) and torch.equal(cp.fwd.plo, ref.plo)
 
 
 # ---------------------------------------------------------------------------------------------- the whole network
