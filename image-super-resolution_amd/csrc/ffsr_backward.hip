@@ -172,25 +172,29 @@ __global__ __launch_bounds__(RB) void coldot_partial_kernel(const float* __restr
     part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // out[c * ostride] = (accumulate ? out : 0) + scale * sum_k part[k * pstride + c]   (double accumulation)
-// block 256 = 64 columns x 4 chunk lanes, grid = ceil(C / 64)
+// block 256 = 32 columns x 8 chunk lanes (four independent chains each: 32 loads of a column in flight), grid = ceil(C / 32)
 __global__ __launch_bounds__(RB) void colsum_finish_kernel(const float* __restrict__ part, int nchunk, int pstride, int C,
                                                            float* __restrict__ out, int ostride, float scale, int accumulate) {
-  __shared__ double red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int kl = threadIdx.x >> 6;
-  double s0 = 0.0, s1 = 0.0;
+  __shared__ double red[8][32];
+  const int l32 = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + l32;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (c < C) {
     int k = kl;
-    for (; k + 4 < nchunk; k += 8) {
+    for (; k + 24 < nchunk; k += 32) {
       s0 += part[(size_t)k * pstride + c];
-      s1 += part[(size_t)(k + 4) * pstride + c];
+      s1 += part[(size_t)(k + 8) * pstride + c];
+      s2 += part[(size_t)(k + 16) * pstride + c];
+      s3 += part[(size_t)(k + 24) * pstride + c];
     }
-    for (; k < nchunk; k += 4) s0 += part[(size_t)k * pstride + c];
+    for (; k < nchunk; k += 8) s0 += part[(size_t)k * pstride + c];
   }
-  red[kl][threadIdx.x & 63] = s0 + s1;
+  red[kl][l32] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (kl == 0 && c < C) {
-    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    double s = red[0][l32];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s += red[j][l32];
     float* o = out + (size_t)c * ostride;
     *o = (accumulate ? *o : 0.f) + (float)(scale * s);
   }
@@ -378,14 +382,36 @@ __global__ __launch_bounds__(RB) void dwconv_wgrad_kernel(const float* __restric
     __syncthreads();
   }
 }
-// dw[c, t] += sum_chunk part[chunk, t, c]      (dw in nn.Conv2d layout [C, 1, KH, KW])
-__global__ void dwconv_wgrad_finish_kernel(const float* __restrict__ part, int nchunk, int T, int C, float* __restrict__ dw) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= T * C) return;
-  const int t = idx / C, c = idx % C;
-  double s = 0.0;
-  for (int k = 0; k < nchunk; ++k) s += part[((size_t)k * T + t) * C + c];
-  dw[(size_t)c * T + t] += (float)s;
+// dw[c, t] += sum_chunk part[chunk, t, c]      (dw in nn.Conv2d layout [C, 1, KH, KW]).  8 threads per output, four independent
+// chains each, combined in a fixed order (a thread per output summed its ~1000 partials as one dependent chain: 60 us)
+__global__ __launch_bounds__(256) void dwconv_wgrad_finish_kernel(const float* __restrict__ part, int nchunk, int T, int C,
+                                                                  float* __restrict__ dw) {
+  __shared__ double red[8][32];
+  const int lane32 = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + lane32;
+  const bool live = idx < T * C;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (live) {
+    const float* pp = part + idx;                      // part[(k * T + t) * C + c] = part[k * T * C + idx]
+    const size_t st = (size_t)T * C;
+    int k = sg;
+    for (; k + 24 < nchunk; k += 32) {
+      s0 += pp[(size_t)k * st];
+      s1 += pp[(size_t)(k + 8) * st];
+      s2 += pp[(size_t)(k + 16) * st];
+      s3 += pp[(size_t)(k + 24) * st];
+    }
+    for (; k < nchunk; k += 8) s0 += pp[(size_t)k * st];
+  }
+  red[sg][lane32] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sg == 0 && live) {
+    double a = red[0][lane32];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) a += red[j][lane32];
+    const int t = idx / C, c = idx % C;
+    dw[(size_t)c * T + t] += (float)a;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- resampler adjoints
@@ -716,7 +742,7 @@ extern "C" int ffsr_coldot_acc_f32(const float* a, int lda, const float* b, int 
                                    int nchunk, float* out, int ostride, float scale, int accumulate, void* stream) {
   FFSR_CHECK(a && part && out && M > 0 && C > 0 && lda >= C && (!b || ldb >= C) && nchunk >= 1 && nchunk <= 65535 && ostride >= 1);
   FFSR_LAUNCH(coldot_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(RB), 0, ST, a, lda, b, ldb, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, out, ostride, scale, accumulate);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, out, ostride, scale, accumulate);
   return ffsr_launch_status();
 }
 
@@ -742,9 +768,9 @@ extern "C" int ffsr_bn_train_stats_f32(const float* x, int ldx, long long M, int
   FFSR_CHECK(!run_mean == !run_var);
   const dim3 g((C + 63) / 64, nchunk);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, (const float*)nullptr, 0, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, x, ldx, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
   FFSR_LAUNCH(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, sums, M, C, gamma, beta, eps, momentum, stat,
               scale_shift, run_mean, run_var);
   return ffsr_launch_status();
@@ -759,9 +785,9 @@ extern "C" int ffsr_bn_train_bwd_f32(const float* x, int ldx, const float* dy, i
              ldy >= C && lddx >= C && nchunk >= 1 && nchunk <= 65535);
   const dim3 g((C + 63) / 64, nchunk);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, (const float*)nullptr, 0, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
   FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, x, ldx, M, C, nchunk, part);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
   FFSR_LAUNCH(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, sums, M, C, gamma, stat, coef, dgamma, dbeta);
   FFSR_LAUNCH(affine2_kernel, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, x, ldx, coef, dx, lddx, M, C);
   return ffsr_launch_status();
@@ -777,8 +803,8 @@ extern "C" int ffsr_layernorm_bwd_f32(const float* x, int ldx, const float* gamm
   long long rpb = (M + nblock - 1) / nblock;
   const int nb = (int)((M + rpb - 1) / rpb);
   FFSR_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(RB), 0, ST, x, ldx, gamma, dy, ldy, dx, lddx, part, M, C, eps, rpb);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part, nb, 2 * C, C, dgamma, 1, 1.f, 1);
-  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(RB), 0, ST, part + C, nb, 2 * C, C, dbeta, 1, 1.f, 1);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nb, 2 * C, C, dgamma, 1, 1.f, 1);
+  FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part + C, nb, 2 * C, C, dbeta, 1, 1.f, 1);
   return ffsr_launch_status();
 }
 
@@ -798,7 +824,7 @@ extern "C" int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, i
     FFSR_LAUNCH((dwconv_wgrad_kernel<3, 3>), g, dim3(RB), 0, ST, x, ldx, dy, ldy, part, B, H, W, C, pad_h, pad_w, nchunk);
   else
     return FFSR_EINVAL;
-  FFSR_LAUNCH(dwconv_wgrad_finish_kernel, dim3(grid_for((long long)KH * KW * C)), dim3(RB), 0, ST, part, nchunk, KH * KW, C, dw);
+  FFSR_LAUNCH(dwconv_wgrad_finish_kernel, dim3((unsigned)((KH * KW * C + 31) / 32)), dim3(256), 0, ST, part, nchunk, KH * KW, C, dw);
   return ffsr_launch_status();
 }
 

@@ -716,25 +716,39 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   }
 }
 
-// dW[n, c, t] += sum_s part[s, t, n, c]
-__global__ void wgrad_finish_kernel(const float* __restrict__ part, int S, int T, int N, int Cin, float* __restrict__ dw) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// dW[n, c, t] += sum_s part[s, t, n, c].  One output per 8 threads: each sums every 8th split (four independent double chains:
+// the loads of one trip are in flight together), the 8 partial sums are added in a fixed order -- a thread per output walked
+// its S partials serially (S / 4 dependent load latencies: 12 - 100 us per layer, 185 layers per training step).
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, int S, int T, int N, int Cin,
+                                                           float* __restrict__ dw) {
+  __shared__ double red[8][32];
+  const int lane32 = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const long long idx = (long long)blockIdx.x * 32 + lane32;
   const long long per = (long long)N * Cin;
-  if (idx >= per * T) return;
-  const int t = (int)(idx / per);
-  const long long nc = idx % per;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;     // independent chains: the loads of one trip are in flight together
-  const float* pp = part + (size_t)t * per + nc;
-  const size_t st = (size_t)T * per;
-  int k = 0;
-  for (; k + 3 < S; k += 4) {
-    s0 += pp[(size_t)k * st];
-    s1 += pp[(size_t)(k + 1) * st];
-    s2 += pp[(size_t)(k + 2) * st];
-    s3 += pp[(size_t)(k + 3) * st];
+  const bool live = idx < per * T;
+  const int t = live ? (int)(idx / per) : 0;
+  const long long nc = live ? idx % per : 0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (live) {
+    const float* pp = part + (size_t)t * per + nc;
+    const size_t st = (size_t)T * per;
+    int k = sg;
+    for (; k + 24 < S; k += 32) {
+      s0 += pp[(size_t)k * st];
+      s1 += pp[(size_t)(k + 8) * st];
+      s2 += pp[(size_t)(k + 16) * st];
+      s3 += pp[(size_t)(k + 24) * st];
+    }
+    for (; k < S; k += 8) s0 += pp[(size_t)k * st];
   }
-  for (; k < S; ++k) s0 += pp[(size_t)k * st];
-  dw[nc * T + t] += (float)((s0 + s1) + (s2 + s3));
+  red[sg][lane32] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sg == 0 && live) {
+    double a = red[0][lane32];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) a += red[j][lane32];
+    dw[nc * T + t] += (float)a;
+  }
 }
 
 template <int WN, int WC, int FN, int FC>
@@ -833,9 +847,9 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   else if (tn == 128 && tc == 64) launch<2, 2, 2, 1>(a, grid, st);
   else launch<2, 2, 2, 2>(a, grid, st);
   const long long nw = (long long)T * N * Cin;
-  FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, partial, (int)S, T, N, Cin, dw);
+  FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, st, partial, (int)S, T, N, Cin, dw);
   if (dbias)
-    FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a.bias_part, (int)S, 1, N, 1, dbias);
+    FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, a.bias_part, (int)S, 1, N, 1, dbias);
   return ffsr_launch_status();
 }
 
