@@ -716,6 +716,213 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   }
 }
 
+// ---- thin 3x3 layers at HR resolution: N <= 4 outputs (refine.10 128 -> 3, the edge / gate heads) or Cin <= 4 inputs (refine.0
+// 3 -> 128) ----------------------------------------------------------------------------------------------------------------------
+// On the MFMA kernels the thin side pads to a 32-wide tile: 8 - 32x the layer's work (2.5 - 2.8 ms per layer at 32 x 256 x 256).
+// Here the gradient is what it is, a streaming outer-product accumulation on the vector ALU, the mirror image of
+// conv3x3_thin_kernel (ffsr_fusion.hip): LPP lanes share a pixel, a lane owns 4 channels of the WIDE side and keeps its slice
+// of dW in registers (N x 9 or 9 x 4 float4 accumulators) while its group walks runs of pixels with a ring of X columns;
+// the thin side's few values per pixel are broadcast loads.  Groups of a block take vertically adjacent rows; a block walks
+// several (row block, run) tiles, sums its groups through LDS in a fixed order and writes ONE partial tile (the finishing
+// kernel adds the blocks in double precision).  Exact fp32 FMA.
+template <int LPP>
+__device__ __forceinline__ void thin_tile(int tile, int runs_per_row, int nyb, int run, int H, int W, int g, int& b, int& y, bool& live,
+                                          int& x0, int& x1) {
+  constexpr int GPB = 256 / LPP;
+  const int xr = tile % runs_per_row, yb = (tile / runs_per_row) % nyb;
+  b = tile / (runs_per_row * nyb);
+  live = yb * GPB + g < H;
+  y = min(yb * GPB + g, H - 1);
+  x0 = xr * run, x1 = min(W, x0 + run);
+}
+
+// N <= 4 outputs, Cin = 4 LPP: dw[n, c, tap] += sum_pix dy[pix, n] x[pix + tap, c]
+template <int N, int LPP>
+__global__ __launch_bounds__(256) void wgrad_thin_out_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int ldy,
+                                                             float* __restrict__ part, float* __restrict__ bias_part, int B, int H, int W,
+                                                             int run, int ntiles) {
+  constexpr int CIN = 4 * LPP, GPB = 256 / LPP, R = N == 4 ? 6 : 8;
+  __shared__ floatx4 red[GPB][9][LPP];
+  const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+  const int runs_per_row = (W + run - 1) / run, nyb = (H + GPB - 1) / GPB;
+  const char* xb_ = reinterpret_cast<const char*>(x);
+  const unsigned ldb = (unsigned)ldx * 4u, cmax = (unsigned)(W - 1) * ldb;
+  const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+  floatx4 acc[N][9];
+  float bs[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    bs[n] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[n][t] = zero;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b, y, x0, x1;
+    bool live;
+    thin_tile<LPP>(tile, runs_per_row, nyb, run, H, W, g, b, y, live, x0, x1);
+    unsigned roff[3];
+    float rowm[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      rowm[ky] = (yy >= 0 && yy < H) ? 1.f : 0.f;          // zero padding: rows / columns outside the image contribute nothing
+      roff[ky] = (unsigned)(((b * H + min(max(yy, 0), H - 1)) * W) * ldx + 4 * l) * 4u;
+    }
+    auto col = [&](int ky, unsigned coff, float m) -> floatx4 {
+      return *reinterpret_cast<const floatx4*>(xb_ + (size_t)(roff[ky] + coff)) * (m * rowm[ky]);
+    };
+    floatx4 ring[R][3];       // columns x-1, x, x+1 = ring[j], [j+1], [j+2]; x+2 .. x+R-3 in flight; x+R-2 issued (conv3x3_thin_kernel)
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) {
+      const int c = x0 - 1 + j;
+      const unsigned coff = (unsigned)min(max(c, 0), W - 1) * ldb;
+      const float m = (c >= 0 && c < W) ? 1.f : 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) ring[j][ky] = col(ky, coff, m);
+    }
+    unsigned coff = (unsigned)min(x0 + R - 2, W - 1) * ldb;
+    const float* dyp = dy + (((size_t)b * H + y) * W) * ldy;
+    const float lm = live ? 1.f : 0.f;
+    auto dyload = [&](int xx) -> floatx4 { return *reinterpret_cast<const floatx4*>(dyp + (size_t)min(xx, W - 1) * ldy); };
+    floatx4 dq[2] = {dyload(x0), dyload(x0 + 1)};          // dY two pixels ahead of its use
+    for (int xb = x0; xb < x1; xb += R) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int xx = xb + j;
+        const float m = (xx + R - 2 < W) ? 1.f : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) ring[(j + R - 1) % R][ky] = col(ky, coff, m);
+        coff = min(coff + ldb, cmax);
+        const floatx4 d4 = dq[j & 1] * (xx < x1 ? lm : 0.f);
+        dq[j & 1] = dyload(xx + 2);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          bs[n] += d4[n];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[n][t] += ring[(j + t % 3) % R][t / 3] * d4[n];
+        }
+      }
+    }
+  }
+  // groups -> one partial tile of the block: part[block][tap][n][c]
+  float* dst = part + (size_t)blockIdx.x * 9 * N * CIN;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[g][t][l] = acc[n][t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * LPP; i += 256) {
+      const int t = i / LPP, ll = i % LPP;
+      floatx4 s = red[0][t][ll];
+#pragma unroll
+      for (int gg = 1; gg < GPB; ++gg) s += red[gg][t][ll];
+      *reinterpret_cast<floatx4*>(dst + ((size_t)t * N + n) * CIN + 4 * ll) = s;
+    }
+  }
+  if (bias_part) {          // every lane of a group holds the same sums: lane 0 of each group speaks
+    __syncthreads();
+    float* rb = reinterpret_cast<float*>(&red[0][0][0]);
+    if (l == 0)
+#pragma unroll
+      for (int n = 0; n < N; ++n) rb[g * N + n] = bs[n];
+    __syncthreads();
+    if (threadIdx.x < N) {
+      float s = 0.f;
+      for (int gg = 0; gg < GPB; ++gg) s += rb[gg * N + threadIdx.x];
+      bias_part[(size_t)blockIdx.x * N + threadIdx.x] = s;
+    }
+  }
+}
+
+// Cin <= 4 inputs (map stride 4), N = 4 LPP outputs: a lane owns 4 output channels, the 9 x 4 input values of a pixel are broadcast loads
+template <int LPP>
+__global__ __launch_bounds__(256) void wgrad_thin_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, int ldy,
+                                                            float* __restrict__ part, float* __restrict__ bias_part, int B, int H, int W,
+                                                            int Cin, int run, int ntiles) {
+  constexpr int NN = 4 * LPP, GPB = 256 / LPP, R = 6;
+  __shared__ floatx4 red[GPB][4][LPP];
+  const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+  const int runs_per_row = (W + run - 1) / run, nyb = (H + GPB - 1) / GPB;
+  const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+  floatx4 acc[9][4], bs = zero;        // [tap][input channel] over the lane's 4 output channels
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = zero;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b, y, x0, x1;
+    bool live;
+    thin_tile<LPP>(tile, runs_per_row, nyb, run, H, W, g, b, y, live, x0, x1);
+    const float* rowp[3];
+    float rowm[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      rowm[ky] = (yy >= 0 && yy < H) ? 1.f : 0.f;
+      rowp[ky] = x + (((size_t)b * H + min(max(yy, 0), H - 1)) * W) * 4;
+    }
+    auto col = [&](int ky, int c) -> floatx4 {
+      return *reinterpret_cast<const floatx4*>(rowp[ky] + (size_t)min(max(c, 0), W - 1) * 4) * ((c >= 0 && c < W) ? rowm[ky] : 0.f);
+    };
+    floatx4 ring[R][3];
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) ring[j][ky] = col(ky, x0 - 1 + j);
+    const float* dyp = dy + (((size_t)b * H + y) * W) * ldy + 4 * l;
+    const float lm = live ? 1.f : 0.f;
+    auto dyload = [&](int xx) -> floatx4 { return *reinterpret_cast<const floatx4*>(dyp + (size_t)min(xx, W - 1) * ldy); };
+    floatx4 dq[2] = {dyload(x0), dyload(x0 + 1)};          // dY two pixels ahead of its use
+    for (int xb = x0; xb < x1; xb += R) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int xx = xb + j;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) ring[(j + R - 1) % R][ky] = col(ky, xx + R - 2);
+        const floatx4 d4 = dq[j & 1] * (xx < x1 ? lm : 0.f);
+        dq[j & 1] = dyload(xx + 2);
+        bs += d4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const floatx4 xv = ring[(j + t % 3) % R][t / 3];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[t][c] += d4 * xv[c];
+        }
+      }
+    }
+  }
+  // part[block][tap][n][c], c < Cin
+  float* dst = part + (size_t)blockIdx.x * 9 * NN * Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[g][c][l] = acc[t][c];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * LPP; i += 256) {
+      const int c = i / LPP, ll = i % LPP;
+      floatx4 s = red[0][c][ll];
+#pragma unroll
+      for (int gg = 1; gg < GPB; ++gg) s += red[gg][c][ll];
+      if (c < Cin)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[((size_t)t * NN + 4 * ll + q) * Cin + c] = s[q];
+    }
+  }
+  if (bias_part) {
+    __syncthreads();
+    red[g][0][l] = bs;
+    __syncthreads();
+    if (threadIdx.x < LPP) {
+      floatx4 s = red[0][0][threadIdx.x];
+#pragma unroll
+      for (int gg = 1; gg < GPB; ++gg) s += red[gg][0][threadIdx.x];
+      *reinterpret_cast<floatx4*>(bias_part + (size_t)blockIdx.x * NN + 4 * threadIdx.x) = s;
+    }
+  }
+}
+
 // dW[n, c, t] += sum_s part[s, t, n, c].  One output per 8 threads: each sums every 8th split (four independent double chains:
 // the loads of one trip are in flight together), the 8 partial sums are added in a fixed order -- a thread per output walked
 // its S partials serially (S / 4 dependent load latencies: 12 - 100 us per layer, 185 layers per training step).
@@ -768,6 +975,64 @@ void launch(const WgradArgs& a, dim3 grid, hipStream_t st) {
 // dy (the bias gradient; null = skip).
 // partial: caller-owned scratch of partial_floats floats (>= KH*KW*N*Cin + N; more lets the pixels be split over more
 // workgroups).
+// thin 3x3 layers at HR resolution on the vector-ALU kernels; returns 1 if it took the layer, 0 if not, < 0 on error
+static int wgrad_thin(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial, long long partial_floats,
+                      int B, int H, int W, int Cin, int N, hipStream_t st) {
+  const long long P = (long long)B * H * W;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0 &&
+                       (ldx % 4 == 0) && (ldy % 4 == 0);
+  if (!aligned || P < 16384 || P * (long long)(ldx > ldy ? ldx : ldy) * 4 >= (1ll << 32)) return 0;
+  const bool thin_out = N <= 4 && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128) && N <= Cin / 4;
+  const bool thin_in = Cin <= 4 && ldx == 4 && (N == 8 || N == 16 || N == 32 || N == 64 || N == 128);
+  if (!thin_out && !thin_in) return 0;
+  const int lpp = (thin_out ? Cin : N) / 4, gpb = 256 / lpp;
+  const int run = W >= 64 ? 32 : (W >= 16 ? 8 : W);
+  const long long ntiles = (long long)B * ((H + gpb - 1) / gpb) * ((W + run - 1) / run);
+  const long long per_block = 9ll * N * Cin + (dbias ? N : 0);
+  long long blocks = ntiles < 1024 ? ntiles : 1024;
+  if (blocks > partial_floats / per_block) blocks = partial_floats / per_block;
+  if (blocks < 1 || ntiles >= (1ll << 31)) return 0;
+  float* bias_part = dbias ? partial + (size_t)blocks * 9 * N * Cin : nullptr;
+  const dim3 grid((unsigned)blocks);
+#define FFSR_THIN_OUT(NV, LPP) \
+  FFSR_LAUNCH((wgrad_thin_out_kernel<NV, LPP>), grid, dim3(256), 0, st, x, ldx, dy, ldy, partial, bias_part, B, H, W, run, (int)ntiles)
+#define FFSR_THIN_OUT_N(LPP)                                                                                     \
+  switch (N) {                                                                                                   \
+    case 1: FFSR_THIN_OUT(1, LPP); break;                                                                        \
+    case 2: FFSR_THIN_OUT(2, LPP); break;                                                                        \
+    case 3: FFSR_THIN_OUT(3, LPP); break;                                                                        \
+    default: FFSR_THIN_OUT(4, LPP); break;                                                                       \
+  }
+#define FFSR_THIN_IN(LPP) \
+  FFSR_LAUNCH((wgrad_thin_in_kernel<LPP>), grid, dim3(256), 0, st, x, dy, ldy, partial, bias_part, B, H, W, Cin, run, (int)ntiles)
+  if (thin_out) {
+    switch (lpp) {
+      case 2: FFSR_THIN_OUT_N(2); break;
+      case 4: FFSR_THIN_OUT_N(4); break;
+      case 8: FFSR_THIN_OUT_N(8); break;
+      case 16: FFSR_THIN_OUT_N(16); break;
+      default: FFSR_THIN_OUT_N(32); break;
+    }
+  } else {
+    switch (lpp) {
+      case 2: FFSR_THIN_IN(2); break;
+      case 4: FFSR_THIN_IN(4); break;
+      case 8: FFSR_THIN_IN(8); break;
+      case 16: FFSR_THIN_IN(16); break;
+      default: FFSR_THIN_IN(32); break;
+    }
+  }
+#undef FFSR_THIN_OUT
+#undef FFSR_THIN_OUT_N
+#undef FFSR_THIN_IN
+  const long long nw = 9ll * N * Cin;
+  FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, st, partial, (int)blocks, 9, N, Cin, dw);
+  if (dbias)
+    FFSR_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, bias_part, (int)blocks, 1, N, 1, dbias);
+  const int rc = ffsr_launch_status();
+  return rc == FFSR_OK ? 1 : rc;
+}
+
 static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                       long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
                       bool split_bf16, void* stream) {
@@ -776,6 +1041,10 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   const int T = KH * KW;
   const long long per_tile = (long long)T * N * Cin + (dbias ? N : 0);     // floats of scratch per pixel split
   FFSR_CHECK(partial_floats >= per_tile);
+  if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && (N <= 4 || Cin <= 4)) {
+    const int took = wgrad_thin(x, ldx, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, (hipStream_t)stream);
+    if (took != 0) return took < 0 ? took : FFSR_OK;
+  }
   WgradArgs a;
   a.x = x, a.dy = dy, a.part = partial, a.bias_part = nullptr, a.ldx = ldx, a.ldy = ldy;
   a.B = B, a.H = H, a.W = W, a.Cin = Cin, a.N = N, a.KH = KH, a.KW = KW, a.ph = pad_h, a.pw = pad_w;

@@ -150,6 +150,29 @@ def test_wgrad_split_bf16_wide_layers(B, H, W, Cin, N):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel(outs[0][0].double(), want) < 3e-5 and rel(outs[0][1].double(), dy.double().sum((0, 2, 3))) < 1e-5
 
+@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 96, 100, 128, 3), (1, 130, 131, 16, 1), (3, 80, 70, 32, 4), (1, 128, 129, 8, 2),
+                                         (2, 96, 100, 3, 128), (1, 150, 113, 4, 32), (2, 90, 95, 1, 8), (1, 200, 90, 64, 3)])
+def test_wgrad_thin_layers(B, H, W, Cin, N):
+    """3x3 layers with N <= 4 outputs (refine.10, the edge / gate heads: enhanced_fusion_v2.py:576, edge_enhancement.py:88,177) or
+    Cin <= 4 inputs (refine.0, enhanced_fusion_v2.py:569) at HR sizes: the vector-ALU outer-product kernels behind both weight-
+    gradient entry points, exact fp32, against fp64 autograd; ragged rows / runs, every border, bias gradient, determinism."""
+    hip = mod("hip")
+    g = gen(B * 100 + Cin + N)
+    x, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, N, H, W, generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (N, Cin, 3, 3), dy.double(), padding=1)
+    xm, dm = to_map(x), to_map(dy)
+    for entry in ("ffsr_conv_wgrad_f32", "ffsr_conv_wgrad_bf16x3"):
+        outs = []
+        for _ in range(2):
+            dw = torch.zeros(N, Cin, 3, 3, device=DEV)
+            part = torch.empty(1 << 23, device=DEV)
+            db = torch.zeros(N, device=DEV)
+            hip.call(entry, xm.data_ptr(), xm.stride(2), dm.data_ptr(), dm.stride(2), dw.data_ptr(), db.data_ptr(),
+                     part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
+            outs.append((dw.cpu(), db.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert rel(outs[0][0].double(), want) < 2e-6 and rel(outs[0][1].double(), dy.double().sum((0, 2, 3))) < 2e-6
+
 # ---------------------------------------------------------------------------------------------- depthwise / norms
 @pytest.mark.parametrize("C,kh,kw,ph,pw_", [(64, 5, 5, 2, 2), (128, 1, 21, 0, 10), (64, 21, 1, 10, 0)])
 def test_dwconv_backward(C, kh, kw, ph, pw_):

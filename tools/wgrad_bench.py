@@ -10,15 +10,16 @@ sys.path.insert(0, "/root/repo")
 hip = importlib.import_module("image-super-resolution_amd.hip")
 dev = "cuda"
 torch.manual_seed(0)
-for (B, H, W, Cin, N) in [(32, 256, 256, 128, 128), (32, 64, 64, 128, 128), (8, 256, 256, 128, 128)]:
-    x = torch.randn(B, H, W, Cin, device=dev)
-    dy = torch.randn(B, H, W, N, device=dev)
+for (B, H, W, Cin, N) in [(32, 256, 256, 128, 128), (32, 64, 64, 128, 128), (8, 256, 256, 128, 128), (32, 256, 256, 128, 3),
+                          (32, 256, 256, 3, 128), (32, 256, 256, 32, 3), (32, 256, 256, 16, 1)]:
+    x = torch.randn(B, H, W, (Cin + 3) // 4 * 4, device=dev)
+    dy = torch.randn(B, H, W, (N + 3) // 4 * 4, device=dev)
     part = torch.empty(1 << 26, device=dev)
     res = {}
     for name in ("ffsr_conv_wgrad_f32", "ffsr_conv_wgrad_bf16x3"):
         def run():
             dw = torch.zeros(N, Cin, 3, 3, device=dev)
-            hip.call(name, x.data_ptr(), Cin, dy.data_ptr(), N, dw.data_ptr(), None, part.data_ptr(), part.numel(), B, H, W, Cin, N,
+            hip.call(name, x.data_ptr(), x.shape[3], dy.data_ptr(), dy.shape[3], dw.data_ptr(), None, part.data_ptr(), part.numel(), B, H, W, Cin, N,
                      3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
             return dw
         res[name] = run()
