@@ -472,7 +472,9 @@ __device__ __forceinline__ wg_short4 wg_tr_read(const unsigned char* base, unsig
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(base + off));
 }
 
-template <int KC>
+// EDGE: N / Cin are not multiples of the tile (76 -> 64, 96 -> 32 at HR): channels past the edge are staged as zeros and the
+// waves / fragments that hold nothing but padding skip their reads and MFMAs.
+template <int KC, bool EDGE>
 __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   typedef unsigned long long mask_t;
   constexpr int TN = 128, TC = 128, KB = KC + 2, NT = 512;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   // written to LDS): no branch per load.
   constexpr int RPT = NT / 32, LA = KC / RPT, LB = (KB + RPT - 1) / RPT, NP = LA + LB;
   const int u = tid & 31, rowt = tid >> 5;
-  // (N and Cin are multiples of the 128 x 128 tile here: no channel edge)
+  const bool n_ok = !EDGE || n0 + 4 * u < p.N, c_ok = !EDGE || c0 + 4 * u < p.Cin;
   const unsigned uoff_chunk = (unsigned)(u >> 1), uoff_half = 8u * (unsigned)(u & 1);
   // Two chunks are under way besides the one being multiplied: chunk c + 1 sits in registers (loaded during the previous
   // iteration) and is converted / written to the other LDS buffer piece by piece; as soon as a piece's registers are free the
@@ -549,11 +551,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   auto fetch_piece = [&](int i) {                      // of chunk "2"; pieces 0 .. LA-1: dY rows, LA .. NP-1: X strip rows
     if (i < LA) {
       const long long g = q02 + rowt + RPT * i;
-      ra[i] = *reinterpret_cast<const floatx4*>(p.dy + (g < p.P ? g : p.P - 1) * p.ldy + n0 + 4 * u);
+      ra[i] = *reinterpret_cast<const floatx4*>(p.dy + (g < p.P ? g : p.P - 1) * p.ldy + (n_ok ? n0 + 4 * u : 0));
     } else if (i < NP) {
       long long g = q02 + shift + rowt + RPT * (i - LA);      // any in-range pixel may be read: invalid taps read the row of zeros
       g = g < 0 ? 0 : (g < p.P ? g : p.P - 1);
-      rb[i - LA] = *reinterpret_cast<const floatx4*>(p.x + g * p.ldx + c0 + 4 * u);
+      rb[i - LA] = *reinterpret_cast<const floatx4*>(p.x + g * p.ldx + (c_ok ? c0 + 4 * u : 0));
     }
   };
   auto put = [&](unsigned char* hi_plane, unsigned char* lo_plane, int row, const floatx4& v) {
@@ -567,13 +569,13 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   auto stash_piece = [&](int buf, int i) {             // of chunk "1": the LDS side of its fetch_piece(i)
     unsigned char* base = wg_smem + buf * STAGE;
     if (i < LA) {
-      const floatx4 v = ((ma1 >> (rowt + RPT * i)) & 1) ? ra[i] : zero4;
+      const floatx4 v = (((ma1 >> (rowt + RPT * i)) & 1) && n_ok) ? ra[i] : zero4;
       if (do_bias) bsum += v;
       put(base, base + A_PLANE, rowt + RPT * i, v);
     } else if (i < NP) {
       const int j = rowt + RPT * (i - LA);
       const long long g = q01 + shift + j;
-      if (j < KB) put(base + 2 * A_PLANE, base + 2 * A_PLANE + B_PLANE, j, (g >= 0 && g < p.P) ? rb[i - LA] : zero4);
+      if (j < KB) put(base + 2 * A_PLANE, base + 2 * A_PLANE + B_PLANE, j, (g >= 0 && g < p.P && c_ok) ? rb[i - LA] : zero4);
     }
   };
 
@@ -617,6 +619,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) dB[kx][rr] = offB[kx][rr] - zoff;
 
+  // which of this wave's two 32-row fragments hold real output channels, given that its 32 columns hold real input channels
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool act_c = !EDGE || c0 + (wave_u & 3) * 32 < p.Cin;
+  const bool act_n[2] = {act_c && (!EDGE || n0 + (wave_u >> 2) * 64 < p.N), act_c && (!EDGE || n0 + (wave_u >> 2) * 64 + 32 < p.N)};
+
   if (nchunks > 0) {
     if (tid < 256)           // the rows of zeros: 2 buffers x 2 planes x 64 dwords
       *reinterpret_cast<unsigned*>(wg_smem + (tid >> 7) * STAGE + 2 * A_PLANE + ((tid >> 6) & 1) * B_PLANE + 256 * KB + 4 * (tid & 63)) = 0u;
@@ -655,25 +662,29 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
         constexpr int s = decltype(s_tag)::value;
         wg_bf16x8 ah[2], al[2];
 #pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
-          ah[fn] = frag(Ahi + 4096 * s, offA[fn]);
-          al[fn] = frag(Alo + 4096 * s, offA[fn]);
-        }
+        for (int fn = 0; fn < 2; ++fn)
+          if (act_n[fn]) {
+            ah[fn] = frag(Ahi + 4096 * s, offA[fn]);
+            al[fn] = frag(Alo + 4096 * s, offA[fn]);
+          }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int slot = 3 * s + kx;
-          unsigned ob[2];
+          if (act_n[0]) {                    // (wave-uniform; always true without EDGE)
+            unsigned ob[2];
 #pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {      // bit 16 s + 4 rr + krow of the tap's mask: the pixel of the row this lane addresses
-            const unsigned m = (unsigned)(mk[kx] >> (16 * s + 4 * rr));
-            ob[rr] = zoff + ((0u - ((m >> krow) & 1u)) & (dB[kx][rr] + 4096u * s));
-          }
-          const wg_bf16x8 bh = frag(Bhi, ob), bl = frag(Blo, ob);
+            for (int rr = 0; rr < 2; ++rr) {      // bit 16 s + 4 rr + krow of the tap's mask: the pixel of the row this lane addresses
+              const unsigned m = (unsigned)(mk[kx] >> (16 * s + 4 * rr));
+              ob[rr] = zoff + ((0u - ((m >> krow) & 1u)) & (dB[kx][rr] + 4096u * s));
+            }
+            const wg_bf16x8 bh = frag(Bhi, ob), bl = frag(Blo, ob);
 #pragma unroll
-          for (int fn = 0; fn < 2; ++fn) {
-            acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fn], bh, acc[kx][fn], 0, 0, 0);
-            acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bl, acc[kx][fn], 0, 0, 0);
-            acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bh, acc[kx][fn], 0, 0, 0);
+            for (int fn = 0; fn < 2; ++fn)
+              if (act_n[fn]) {
+                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fn], bh, acc[kx][fn], 0, 0, 0);
+                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bl, acc[kx][fn], 0, 0, 0);
+                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bh, acc[kx][fn], 0, 0, 0);
+              }
           }
 #pragma unroll
           for (int i = 0; i < PPER; ++i) {
@@ -698,7 +709,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
       float t = 0.f;
 #pragma unroll
       for (int j = 0; j < RPT; ++j) t += red[j * TN + tid];
-      p.bias_part[(size_t)split * p.N + n0 + tid] = t;
+      if (!EDGE || n0 + tid < p.N) p.bias_part[(size_t)split * p.N + n0 + tid] = t;
     }
   }
   const int T = p.KH * 3, r = lane & 31, h = lane >> 5;
@@ -711,7 +722,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn * 64 + fn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        dst[(size_t)n * p.Cin + c] = acc[kx][fn][e];
+        if (!EDGE || (n < p.N && c < p.Cin)) dst[(size_t)n * p.Cin + c] = acc[kx][fn][e];
       }
   }
 }
@@ -1051,10 +1062,13 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   a.P = (long long)B * H * W;
   const int tn = N <= 32 ? 32 : (N <= 64 ? 64 : 128), tc = Cin <= 32 ? 32 : (Cin <= 64 ? 64 : 128);
   a.n_tiles = (N + tn - 1) / tn, a.c_tiles = (Cin + tc - 1) / tc;
+  // (wide3, below, always works on 128 x 128 tiles)
   // thin 3-wide layers (one 32 x 32 MFMA tile per wave): the three horizontal taps share a workgroup (conv_wgrad3_kernel)
   const bool row3 = KW == 3 && pad_w == 1 && (tn / 32) * (tc / 32) <= 4 && W >= 2;
   // wide 3-wide layers in split-bf16 mode: the transposing-read bf16 kernel (float4 staging: 4-channel units, 16-byte rows)
-  const bool wide3 = split_bf16 && KW == 3 && pad_w == 1 && W >= 2 && (N % 128 == 0) && (Cin % 128 == 0) &&
+  const bool wide_full = (N % 128 == 0) && (Cin % 128 == 0);
+  const bool wide_edge = !wide_full && (N % 4 == 0) && (Cin % 4 == 0) && (N > 64 || Cin > 64) && N >= 32 && Cin >= 32 && (long long)B * H * W >= 65536;
+  const bool wide3 = split_bf16 && KW == 3 && pad_w == 1 && W >= 2 && (wide_full || wide_edge) &&
                      (ldx % 4 == 0) && (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
   const long long tiles = (long long)a.n_tiles * a.c_tiles * ((row3 || wide3) ? KH : T);
   // splits: enough workgroups to fill the chip a few times, at least 256 pixels each, bounded by the scratch.  The MFMA pipe
@@ -1093,12 +1107,15 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
     constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 64;
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
         return FFSR_ELAUNCH;
       attr_set = true;
     }
-    FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW>), grid, dim3(512), LDS, st, a);
+    if (wide_full) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, false>), grid, dim3(512), LDS, st, a);
+    else FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, true>), grid, dim3(512), LDS, st, a);
   } else if (row3) {
     if (tn == 32 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<1, 1, 64>), grid, dim3(256), 0, st, a);
     else if (tn == 32 && tc == 64) FFSR_LAUNCH((conv_wgrad3_kernel<1, 2, 16>), grid, dim3(256), 0, st, a);

@@ -127,12 +127,13 @@ def test_wgrad_large_pixel_count_is_split_deterministically():
 
 
 @pytest.mark.parametrize("B,H,W,Cin,N", [(2, 64, 256, 128, 128), (1, 37, 53, 128, 128), (1, 20, 64, 256, 128), (2, 5, 300, 128, 256),
-                                         (3, 9, 7, 132, 200)])
+                                         (3, 9, 7, 132, 200), (1, 260, 256, 76, 64), (1, 256, 257, 96, 32), (1, 256, 256, 132, 200)])
 def test_wgrad_split_bf16_wide_layers(B, H, W, Cin, N):
     """ffsr_conv_wgrad_bf16x3: 3-wide layers whose channel counts are multiples of the 128 x 128 tile take the transposing-read
     bf16 kernel (three split products), everything about the contract unchanged: image borders (every row / column position of
     the taps), images narrower / wider than a 64-pixel chunk, ragged last chunk and split, several tiles, the bias gradient,
-    run-to-run determinism; the last case (132 -> 200) is a shape without such a kernel: same entry point, exact fp32 path.
+    run-to-run determinism; channel counts off the tile at HR pixel counts (76 -> 64, 96 -> 32: hierarchical_fusion.py, edge_enhancement.py)
+    take the same kernel with the padding fragments skipped; 132 -> 200 on 189 pixels has no such kernel: exact fp32 path.
     Truth = fp64 autograd; the error of three-term split-bf16 products is ~1e-5 relative."""
     hip = mod("hip")
     g = gen(B * 1000 + W)

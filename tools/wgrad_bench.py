@@ -10,7 +10,7 @@ sys.path.insert(0, "/root/repo")
 hip = importlib.import_module("image-super-resolution_amd.hip")
 dev = "cuda"
 torch.manual_seed(0)
-for (B, H, W, Cin, N) in [(32, 256, 256, 128, 128), (32, 64, 64, 128, 128), (8, 256, 256, 128, 128), (32, 256, 256, 128, 3),
+for (B, H, W, Cin, N) in [(32, 256, 256, 128, 128), (32, 64, 64, 128, 128), (8, 256, 256, 128, 128), (32, 256, 256, 76, 64), (32, 256, 256, 96, 32), (32, 256, 256, 128, 3),
                           (32, 256, 256, 3, 128), (32, 256, 256, 32, 3), (32, 256, 256, 16, 1)]:
     x = torch.randn(B, H, W, (Cin + 3) // 4 * 4, device=dev)
     dy = torch.randn(B, H, W, (N + 3) // 4 * 4, device=dev)
