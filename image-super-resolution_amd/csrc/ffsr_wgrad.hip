@@ -1104,7 +1104,7 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   const dim3 grid((unsigned)(tiles * S));
   hipStream_t st = (hipStream_t)stream;
   if (wide3) {
-    constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 64;
+    constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 128;   // two stages + the 4 x 4 chunk masks
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false>),
