@@ -261,6 +261,67 @@ class Tape:
         self._rec(bw)
         return y
 
+    def gelu_conv_chain(self, x: Var, ps: Sequence[ConvP]) -> Var:
+        """conv -> GELU -> conv -> GELU ... (the refine stack, enhanced_fusion_v2.py:569-576).  Where consecutive layers are wide
+        3x3 layers (the planes tap-strip kernel's shapes) the activation between them lives as bf16 planes ONLY: the producing
+        GEMM's epilogue writes the pre-activation z in fp32 (kept for GELU's backward) and GELU(z) as planes, which the next layer's
+        forward GEMM and weight-gradient kernel both read -- no GELU pass, no split pass, no fp32 copy.  Other layers, other modes
+        (FFSR_GEMM_MODE=f32, FFSR_PLANES=0): plain Tape.conv."""
+        def planes_layer(p):
+            return (ops.GEMM_MODE == "bf16x3" and ops.PLANES_AUTO and WGRAD_BF16X3 and p.KH == 3 and p.KW == 3 and p.pad == 1
+                    and p.fwd.phi is not None and p.N % 128 == 0 and p.Cin % 128 == 0)
+        B, H, W, _ = x.v.shape
+        M = B * H * W
+        if M < 65536 or not any(planes_layer(p) for p in ps):
+            for p in ps:
+                x = self.conv(x, p, act=ACT_GELU)
+            return x
+        i, n = 0, len(ps)
+        while i < n:
+            if not planes_layer(ps[i]):
+                x = self.conv(x, ps[i], act=ACT_GELU)
+                i += 1
+                continue
+            j = i
+            while j < n and planes_layer(ps[j]):
+                j += 1
+            x = self._planes_run(x, ps[i:j])
+            i = j
+        return x
+
+    def _planes_run(self, x: Var, ps: Sequence[ConvP]) -> Var:
+        B, H, W, _ = x.v.shape
+        xp = ops.split_planes(x.v)
+        ins, zs = [], []
+        for k, p in enumerate(ps):
+            last = k == len(ps) - 1
+            ins.append(xp)
+            if last:       # the consumer of the run's output wants an fp32 map
+                z = ops.conv2d(xp, p.fwd)
+                y = ops.unary(z, act=ACT_GELU)
+            else:
+                z, xp = ops.conv2d(xp, p.fwd, act=ACT_GELU, out_planes=True, want_f32=True, pre_act_out=True)
+            zs.append(z)
+        out = Var(y)
+
+        def bw():
+            if out.g is None:
+                return
+            gy = out.g
+            for k in range(len(ps) - 1, -1, -1):
+                p = ps[k]
+                gz = self.act_bwd(gy, zs[k], ACT_GELU, 0.0, from_output=False)
+                part = torch.empty(max((p.weight.v.numel() + p.N) * 256, 1 << 20), device=self.device)
+                hip.call("ffsr_conv_wgrad_bf16x3_planes", _ptr(ins[k].hi), _ptr(ins[k].lo), ins[k].Cp, _ptr(gz), ops.ld(gz),
+                         _ptr(p.weight.g), None if p.bias is None else _ptr(p.bias.g), _ptr(part), part.numel(), B, H, W, p.Cin, p.N,
+                         p.KH, p.KW, p.pad, p.pad, _stream())
+                if k > 0 or x.req:
+                    gy = ops.conv2d(gz, p.bwd, tile_hint=0)
+            if x.req:
+                self.acc(x, gy)
+        self._rec(bw)
+        return out
+
     def linear(self, x: Var, p: ConvP, act=ACT_NONE) -> Var:
         return self.conv(x, p, act)
 

@@ -74,6 +74,7 @@ struct PlaneArgs {
   int N, Ho, Wo, ldo, ldr, ldp;
   int KH, KW, stride, pad_h, pad_w;
   int act;
+  int pre_out;                  // 1: the fp32 output receives the PRE-activation value, the planes the activated one (training: z and GELU(z))
   float slope, cscale, rscale;
   int M, nk;                    // nk = taps * Cp / 32
 #ifdef FFSR_PLANES_PROBE
@@ -146,12 +147,14 @@ __device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&a
       floatx16 v = acc[im][jn];
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] += bia;
-      if constexpr (GELU) {
+      if (!p.pre_out) {                            // (wave-uniform; pre_out: the activation is applied to the plane values below)
+        if constexpr (GELU) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-      } else {
+          for (int e = 0; e < 16; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+          for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = v[e] * cs_;
@@ -177,6 +180,18 @@ __device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&a
             *reinterpret_cast<floatx4*>(op + 4) = o1;
           }
           if (p.o_hi) {
+            if (p.pre_out) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if constexpr (GELU) {
+                  o0[c] = 0.5f * o0[c] * (1.0f + erff(o0[c] * 0.70710678118654752440f));
+                  o1[c] = 0.5f * o1[c] * (1.0f + erff(o1[c] * 0.70710678118654752440f));
+                } else {
+                  o0[c] = o0[c] > 0.f ? o0[c] : o0[c] * p.slope;
+                  o1[c] = o1[c] > 0.f ? o1[c] : o1[c] * p.slope;
+                }
+              }
+            }
             unsigned hh[4], ll[4];
             split2(o0[0], o0[1], hh[0], ll[0]);
             split2(o0[2], o0[3], hh[1], ll[1]);
@@ -200,6 +215,7 @@ __device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&a
                 if (p.res) o += p.res[(size_t)m * p.ldr + n] * (p.rvec ? p.rvec[n] : 1.f) * p.rscale;
                 if (p.out) p.out[(size_t)m * p.ldo + n] = o;
               }
+              if (p.pre_out) o = GELU ? 0.5f * o * (1.0f + erff(o * 0.70710678118654752440f)) : (o > 0.f ? o : o * p.slope);
               x[d] = o;
             }
             if (p.o_hi && nn + c < ldp) {   // ldp is even: pairs are whole; columns >= N are written as zeros
@@ -715,6 +731,10 @@ extern "C" int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, co
   a.Wo = (W + 2 * pad_w - KW) / stride + 1;
   FFSR_CHECK(a.Ho > 0 && a.Wo > 0);
   a.ldo = ldo; a.ldr = ldr; a.ldp = ldp; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.pre_out = (act & 0x100) ? 1 : 0;
+  act &= 0xff;
+  // (act | 0x100: fp32 output = pre-activation, planes = activated; no residual / scales in that mode)
+  FFSR_CHECK(!a.pre_out || (out && out_hi && !res && !cvec && cscale == 1.0f));
   a.act = act; a.slope = slope; a.cscale = cscale; a.rscale = rscale;
   const long long M = (long long)B * a.Ho * a.Wo;
   FFSR_CHECK(M < (1ll << 31));

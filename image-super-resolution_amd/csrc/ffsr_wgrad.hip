@@ -25,6 +25,9 @@ constexpr int KC = 16;   // pixels per staged chunk
 
 struct WgradArgs {
   const float* x;
+  const unsigned short* x_hi;   // X as bf16 hi / lo planes [pixels][ldp] instead of x (conv_wgrad3_bf16x3_kernel<.., XPL = true> only)
+  const unsigned short* x_lo;
+  int ldp;
   const float* dy;
   float* part;
   float* bias_part;     // [splits][N] column sums of dY (bias gradient) or null
@@ -474,7 +477,8 @@ __device__ __forceinline__ wg_short4 wg_tr_read(const unsigned char* base, unsig
 
 // EDGE: N / Cin are not multiples of the tile (76 -> 64, 96 -> 32 at HR): channels past the edge are staged as zeros and the
 // waves / fragments that hold nothing but padding skip their reads and MFMAs.
-template <int KC, bool EDGE>
+// XPL: X arrives as bf16 hi / lo planes (the layer's forward input as the planes GEMM consumed it): its rows go to LDS as they are.
+template <int KC, bool EDGE, bool XPL>
 __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   typedef unsigned long long mask_t;
   constexpr int TN = 128, TC = 128, KB = KC + 2, NT = 512;
@@ -555,7 +559,13 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
     } else if (i < NP) {
       long long g = q02 + shift + rowt + RPT * (i - LA);      // any in-range pixel may be read: invalid taps read the row of zeros
       g = g < 0 ? 0 : (g < p.P ? g : p.P - 1);
-      rb[i - LA] = *reinterpret_cast<const floatx4*>(p.x + g * p.ldx + (c_ok ? c0 + 4 * u : 0));
+      if constexpr (XPL) {
+        const size_t o = (size_t)g * p.ldp + (c_ok ? c0 + 4 * u : 0);
+        const wg_uint2 h = *reinterpret_cast<const wg_uint2*>(p.x_hi + o), l2 = *reinterpret_cast<const wg_uint2*>(p.x_lo + o);
+        rb[i - LA] = __builtin_bit_cast(floatx4, wg_uint4{h[0], h[1], l2[0], l2[1]});
+      } else {
+        rb[i - LA] = *reinterpret_cast<const floatx4*>(p.x + g * p.ldx + (c_ok ? c0 + 4 * u : 0));
+      }
     }
   };
   auto put = [&](unsigned char* hi_plane, unsigned char* lo_plane, int row, const floatx4& v) {
@@ -575,7 +585,17 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
     } else if (i < NP) {
       const int j = rowt + RPT * (i - LA);
       const long long g = q01 + shift + j;
-      if (j < KB) put(base + 2 * A_PLANE, base + 2 * A_PLANE + B_PLANE, j, (g >= 0 && g < p.P && c_ok) ? rb[i - LA] : zero4);
+      const floatx4 v = (g >= 0 && g < p.P && c_ok) ? rb[i - LA] : zero4;
+      if constexpr (XPL) {
+        if (j < KB) {
+          const wg_uint4 w = __builtin_bit_cast(wg_uint4, v);
+          const unsigned o = wg_img_off(j, (int)uoff_chunk) + uoff_half;
+          *reinterpret_cast<wg_uint2*>(base + 2 * A_PLANE + o) = wg_uint2{w[0], w[1]};
+          *reinterpret_cast<wg_uint2*>(base + 2 * A_PLANE + B_PLANE + o) = wg_uint2{w[2], w[3]};
+        }
+      } else {
+        if (j < KB) put(base + 2 * A_PLANE, base + 2 * A_PLANE + B_PLANE, j, v);
+      }
     }
   };
 
@@ -1046,17 +1066,24 @@ static int wgrad_thin(const float* x, int ldx, const float* dy, int ldy, float* 
 
 static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                       long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
-                      bool split_bf16, void* stream) {
+                      bool split_bf16, void* stream, const void* x_hi = nullptr, const void* x_lo = nullptr, int ldp = 0) {
+  const bool xpl = x_hi != nullptr;
+  if (xpl) {
+    FFSR_CHECK(x_lo && !x && (ldp & 31) == 0 && ldp >= Cin && split_bf16 &&
+               ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo)) & 15) == 0);
+    x = dy, ldx = Cin;        // (placeholders for the shared checks below: the planes kernel never reads x)
+  }
   FFSR_CHECK(x && dy && dw && partial && B > 0 && H > 0 && W > 0 && Cin > 0 && N > 0 && KH > 0 && KW > 0 && ldx >= Cin && ldy >= N);
   FFSR_CHECK(pad_h >= 0 && pad_w >= 0 && pad_h < KH && pad_w < KW && (long long)B * H * W < (1ll << 31) - 64);
   const int T = KH * KW;
   const long long per_tile = (long long)T * N * Cin + (dbias ? N : 0);     // floats of scratch per pixel split
   FFSR_CHECK(partial_floats >= per_tile);
-  if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && (N <= 4 || Cin <= 4)) {
+  if (!xpl && KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && (N <= 4 || Cin <= 4)) {
     const int took = wgrad_thin(x, ldx, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, (hipStream_t)stream);
     if (took != 0) return took < 0 ? took : FFSR_OK;
   }
   WgradArgs a;
+  a.x_hi = (const unsigned short*)x_hi, a.x_lo = (const unsigned short*)x_lo, a.ldp = ldp;
   a.x = x, a.dy = dy, a.part = partial, a.bias_part = nullptr, a.ldx = ldx, a.ldy = ldy;
   a.B = B, a.H = H, a.W = W, a.Cin = Cin, a.N = N, a.KH = KH, a.KW = KW, a.ph = pad_h, a.pw = pad_w;
   a.P = (long long)B * H * W;
@@ -1070,6 +1097,7 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   const bool wide_edge = !wide_full && (N % 4 == 0) && (Cin % 4 == 0) && (N > 64 || Cin > 64) && N >= 32 && Cin >= 32 && (long long)B * H * W >= 65536;
   const bool wide3 = split_bf16 && KW == 3 && pad_w == 1 && W >= 2 && (wide_full || wide_edge) &&
                      (ldx % 4 == 0) && (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+  if (xpl && !wide3) return FFSR_EINVAL;     // planes input: only the shapes the bf16 kernel takes
   const long long tiles = (long long)a.n_tiles * a.c_tiles * ((row3 || wide3) ? KH : T);
   // splits: enough workgroups to fill the chip a few times, at least 256 pixels each, bounded by the scratch.  The MFMA pipe
   // of a SIMD serves its resident waves one after the other, so the kernel takes as long as the CU that hosts the most
@@ -1107,15 +1135,18 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
     constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 128;   // two stages + the 4 x 4 chunk masks
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-        return FFSR_ELAUNCH;
+      const void* fns[4] = {reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, false>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, false>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, true>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, true>)};
+      for (const void* fn : fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return FFSR_ELAUNCH;
       attr_set = true;
     }
-    if (wide_full) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, false>), grid, dim3(512), LDS, st, a);
-    else FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, true>), grid, dim3(512), LDS, st, a);
+    if (wide_full && !xpl) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, false, false>), grid, dim3(512), LDS, st, a);
+    else if (!xpl) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, true, false>), grid, dim3(512), LDS, st, a);
+    else if (wide_full) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, false, true>), grid, dim3(512), LDS, st, a);
+    else FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, true, true>), grid, dim3(512), LDS, st, a);
   } else if (row3) {
     if (tn == 32 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<1, 1, 64>), grid, dim3(256), 0, st, a);
     else if (tn == 32 && tc == 64) FFSR_LAUNCH((conv_wgrad3_kernel<1, 2, 16>), grid, dim3(256), 0, st, a);
@@ -1151,4 +1182,15 @@ extern "C" int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, 
                                       long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
                                       int pad_w, void* stream) {
   return wgrad_impl(x, ldx, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, KH, KW, pad_h, pad_w, true, stream);
+}
+
+// ffsr_conv_wgrad_bf16x3 with X given as the bf16 hi / lo planes [B*H*W, ldp] the planes GEMM consumed in the forward pass (ldp % 32
+// == 0, pad channels zero): the rows go to LDS as they are, no fp32 copy of the activation has to exist.  Only the shapes the
+// bf16 kernel takes (3-wide, N and Cin multiples of 4, one of them > 64, both >= 32, >= 65536 pixels unless multiples of 128);
+// FFSR_EINVAL otherwise.
+extern "C" int ffsr_conv_wgrad_bf16x3_planes(const void* x_hi, const void* x_lo, int ldp, const float* dy, int ldy, float* dw,
+                                             float* dbias, float* partial, long long partial_floats, int B, int H, int W, int Cin,
+                                             int N, int KH, int KW, int pad_h, int pad_w, void* stream) {
+  return wgrad_impl(nullptr, 0, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, KH, KW, pad_h, pad_w, true, stream,
+                    x_hi, x_lo, ldp);
 }

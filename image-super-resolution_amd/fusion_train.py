@@ -404,8 +404,6 @@ class FusionTrainNet:
         bw_ = t.affine(t.bilinear(diff, Hh, Wh), 0.4, 0.3)
         fused = t.add(fused0, t.mul(t.add(dyn, fused0, 1.0, -1.0), bw_, row_broadcast=True))
         # 7: refine stack, fused + 0.1 * refine(fused) (:781)
-        r = fused
-        for cv in self.refine[:-1]:
-            r = t.conv(r, cv, act=ACT_GELU)
+        r = t.gelu_conv_chain(fused, self.refine[:-1])
         refined = t.add(fused, t.conv(r, self.refine[-1]), 1.0, 0.1)
         return self.laplacian_refine(t, refined, lr)

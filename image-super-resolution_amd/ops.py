@@ -284,12 +284,13 @@ PLANES_AUTO = os.environ.get("FFSR_PLANES", "1") != "0"   # FFSR_PLANES=0: every
 def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] = None,
            res: Optional[torch.Tensor] = None, cvec=None, rvec=None, cscale=1.0, rscale=1.0, shuffle=0,
            akscale: Optional[torch.Tensor] = None, tile_hint=0, out_planes=None, want_f32=True, bm=0, bn=0, stages=0,
-           gate=False):
+           gate=False, pre_act_out=False):
     """x [B,H,W,>=Cin] fp32 map or Planes -> [B,Ho,Wo,N] (or [B,2Ho,2Wo,N/4] with shuffle=2).
     gate=True (split-bf16 mode, fp32 input, weights packed with gate_pairs=True): the store multiplies the two channel
     halves (NAFNet's SimpleGate) -> [B,Ho,Wo,N/2]; res / cvec / rvec refer to the N/2 output channels.
     out_planes: True / a Planes object -> also emit the result as bf16 hi / lo planes (returned as (out, planes), or
-    only the planes when want_f32 is False)."""
+    only the planes when want_f32 is False).
+    pre_act_out (Planes input, both outputs): the fp32 map receives the pre-activation z, the planes act(z)."""
     B, H, W, _ = x.shape
     Ho = (H + 2 * cv.pad - cv.KH) // cv.stride + 1
     Wo = (W + 2 * cv.pad - cv.KW) // cv.stride + 1
@@ -347,8 +348,11 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
                  _ptr(zero_page(dev_)), _ptr(cv.bias), _ptr(out), _ptr(res), _ptr(cvec), _ptr(rvec),
                  None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
                  0 if out_planes is None else out_planes.Cp, B, H, W, cv.N, 0 if out is None else ld(out), ldr, cv.KH,
-                 cv.KW, cv.stride, cv.pad, cv.pad, act, float(slope), float(cscale), float(rscale), *tile, _stream())
+                 cv.KW, cv.stride, cv.pad, cv.pad, act | (0x100 if pre_act_out else 0), float(slope), float(cscale), float(rscale),
+                 *tile, _stream())
     else:
+        if pre_act_out:
+            raise ValueError("pre_act_out needs a Planes input")
         ldi = ld(x)
         assert ldi >= cv.Cin, f"input stride {ldi} < packed Cin {cv.Cin}"
         akrows = 0

@@ -60,7 +60,9 @@ int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, 
  * operands then go global -> LDS by LDS-DMA with no vector-ALU work in the main loop.  Weights: bf16 planes
  * [n_rows_padded, KH*KW*Cp] (tap-major, Cp channels per tap, zero padded; n_rows_padded % bn == 0).  Outputs: fp32
  * `out` (may be NULL) and / or bf16 planes out_hi / out_lo [M, ldp] (may be NULL; ldp = N rounded up to 32, columns
- * >= N are written as zeros) for a following ffsr_conv2d_planes.  act: 0 none, 1 GELU, 2 ReLU, 3 LeakyReLU only.
+ * >= N are written as zeros) for a following ffsr_conv2d_planes.  act: 0 none, 1 GELU, 2 ReLU, 3 LeakyReLU only;
+ * act | 0x100 (both outputs given, no res / cvec / cscale): `out` receives the PRE-activation z, the planes act(z) -- the
+ * training step keeps z for the activation's backward and hands act(z) to the next layer without an fp32 round trip.
  * bm x bn = 128 / 256 rows x 64 / 128 / 192 / 256 columns tile (bm 0 = 128); stages = LDS pipeline depth (0 = default:
  * 2; 2 or 3), or 4 = the tap-strip variant for 3x3 / stride 1 / pad 1 convolutions (bm 128, bn 64 or 128 only): one
  * staged strip of A rows serves the three horizontal taps.  Replaces the same reference calls as
@@ -304,6 +306,12 @@ int ffsr_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float
 int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                            long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
                            void* stream);
+/* ffsr_conv_wgrad_bf16x3 with X given as the bf16 hi / lo planes [B*H*W, ldp] that ffsr_conv2d_planes consumed in the forward
+ * pass (ldp % 32 == 0, pad channels zero): no fp32 copy of the activation has to exist (the refine stack's GELU outputs,
+ * enhanced_fusion_v2.py:569-576, live as planes only).  Shapes: the ones the bf16 kernel takes (see above); FFSR_EINVAL else. */
+int ffsr_conv_wgrad_bf16x3_planes(const void* x_hi, const void* x_lo, int ldp, const float* dy, int ldy, float* dw, float* dbias,
+                                  float* partial, long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW,
+                                  int pad_h, int pad_w, void* stream);
 /* Depthwise (groups = C) weight gradient for the kernel shapes 5x5, 1x21, 21x1 (large_kernel_attention.py:58-76) and 3x3.
  * partial: nchunk * KH*KW * C floats. */
 int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial, int nchunk, int B, int H,
