@@ -151,6 +151,34 @@ def test_wgrad_split_bf16_wide_layers(B, H, W, Cin, N):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel(outs[0][0].double(), want) < 3e-5 and rel(outs[0][1].double(), dy.double().sum((0, 2, 3))) < 1e-5
 
+@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 64, 256, 128, 128), (1, 37, 53, 128, 256), (1, 260, 256, 96, 128)])
+def test_wgrad_from_planes_matches_fp32_input(B, H, W, Cin, N):
+    """ffsr_conv_wgrad_bf16x3_planes: X given as the bf16 hi / lo planes the forward GEMM consumed -- the same staged bits as
+    ffsr_conv_wgrad_bf16x3 makes of the fp32 map, so the results are bit-identical; shapes without a bf16 kernel are refused."""
+    hip, ops = mod("hip"), mod("ops")
+    g = gen(B + Cin + N)
+    x, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, N, H, W, generator=g)
+    xm, dm = to_map(x), to_map(dy)
+    xp = ops.split_planes(xm)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for planes in (False, True):
+        dw, db = torch.zeros(N, Cin, 3, 3, device=DEV), torch.zeros(N, device=DEV)
+        part = torch.empty(1 << 24, device=DEV)
+        if planes:
+            hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, dm.data_ptr(), dm.stride(2),
+                     dw.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, st)
+        else:
+            hip.call("ffsr_conv_wgrad_bf16x3", xm.data_ptr(), xm.stride(2), dm.data_ptr(), dm.stride(2), dw.data_ptr(),
+                     db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, st)
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want = torch.nn.grad.conv2d_weight(x.double(), (N, Cin, 3, 3), dy.double(), padding=1)
+    assert rel(outs[1][0].double(), want) < 3e-5
+    with pytest.raises(Exception):      # 1x1: no bf16 weight-gradient kernel
+        hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, dm.data_ptr(), dm.stride(2),
+                 dw.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 1, 1, 0, 0, st)
+
 @pytest.mark.parametrize("B,H,W,Cin,N", [(2, 96, 100, 128, 3), (1, 130, 131, 16, 1), (3, 80, 70, 32, 4), (1, 128, 129, 8, 2),
                                          (2, 96, 100, 3, 128), (1, 150, 113, 4, 32), (2, 90, 95, 1, 8), (1, 200, 90, 64, 3)])
 def test_wgrad_thin_layers(B, H, W, Cin, N):

@@ -209,3 +209,22 @@ def test_planes_entry_points_reject_bad_arguments(ops, pkg):
     with pytest.raises(hip.FfsrError, match="invalid argument"):           # LayerNorm planes need the vectorised path
         hip.call("ffsr_layernorm_planes_f32", x.data_ptr(), 180, x.data_ptr(), x.data_ptr(), 1e-5, None, 0, xp.hi.data_ptr(),
                  xp.lo.data_ptr(), 160, None, 0, None, 0, None, 0, 64, 180, torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("act,N,k", [(1, 128, 3), (1, 180, 1), (3, 45, 1), (2, 128, 3)])
+def test_pre_activation_fp32_with_activated_planes(ops, E, act, N, k):
+    """act | 0x100 (the training step's refine stack): the fp32 output is the PRE-activation z, bit-identical to the launch
+    without activation, and the planes are split(act(z)) -- tile kernel, tap-strip kernel, vector and edge store paths."""
+    B, H, W, C = 2, 96, 100, 128
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, k, k, seed=2, scale=0.05), rnd(N, seed=3)
+    cv = ops.pack_conv(w, b, DEV)
+    xp = ops.split_planes(E.nchw_to_map(x, DEV))
+    plain = ops.conv2d(xp, cv)
+    z, pl = ops.conv2d(xp, cv, act=act, slope=0.2, out_planes=True, want_f32=True, pre_act_out=True)
+    assert torch.equal(z, plain)
+    want = ACT[act](z[..., :N].float())
+    got = pl.hi[:, :N].float() + pl.lo[:, :N].float()
+    assert (got.reshape(B, H, W, N) - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert (pl.buf[:, :, N:] == 0).all()
+    with pytest.raises(Exception):
+        ops.conv2d(xp, cv, act=act, out_planes=True, want_f32=True, pre_act_out=True, res=plain)   # no residual in this mode
