@@ -310,13 +310,17 @@ class Tape:
             gy = out.g
             for k in range(len(ps) - 1, -1, -1):
                 p = ps[k]
-                gz = self.act_bwd(gy, zs[k], ACT_GELU, 0.0, from_output=False)
+                # dZ = dY * GELU'(z) straight to planes: the input-gradient GEMM and the weight-gradient kernel both read them
+                gz = ops.Planes(B, H, W, p.N, self.device)
+                _, Mr, C, ldg = _mat(gy)
+                hip.call("ffsr_act_bwd_planes_f32", _ptr(gy), ldg, _ptr(zs[k]), _mat(zs[k])[3], _ptr(gz.hi), _ptr(gz.lo), gz.Cp, Mr, C,
+                         ACT_GELU, 0.0, 0, 1.0, _stream())
                 part = torch.empty(max((p.weight.v.numel() + p.N) * 256, 1 << 20), device=self.device)
-                hip.call("ffsr_conv_wgrad_bf16x3_planes", _ptr(ins[k].hi), _ptr(ins[k].lo), ins[k].Cp, _ptr(gz), ops.ld(gz),
-                         _ptr(p.weight.g), None if p.bias is None else _ptr(p.bias.g), _ptr(part), part.numel(), B, H, W, p.Cin, p.N,
-                         p.KH, p.KW, p.pad, p.pad, _stream())
+                hip.call("ffsr_conv_wgrad_bf16x3_planes", _ptr(ins[k].hi), _ptr(ins[k].lo), ins[k].Cp, None, 0, _ptr(gz.hi), _ptr(gz.lo),
+                         gz.Cp, _ptr(p.weight.g), None if p.bias is None else _ptr(p.bias.g), _ptr(part), part.numel(), B, H, W,
+                         p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
                 if k > 0 or x.req:
-                    gy = ops.conv2d(gz, p.bwd, tile_hint=0)
+                    gy = ops.conv2d(gz, p.bwd)
             if x.req:
                 self.acc(x, gy)
         self._rec(bw)

@@ -98,6 +98,27 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int ldy, const floa
   }
 }
 
+// The same with the result written as bf16 hi / lo planes [M, ldp] (ldp == C, C % 32 == 0): dY of a wide layer goes straight to the
+// planes GEMM (input gradient) and the planes weight-gradient kernel, no fp32 copy and no split pass.  8 channels per thread.
+__global__ void act_bwd_planes_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ ref, int ldr,
+                                      unsigned short* __restrict__ o_hi, unsigned short* __restrict__ o_lo, int ldp, long long M, int C,
+                                      int act, float slope, int from_output, float alpha) {
+  const int cv = C / 8;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * cv) return;
+  const long long m = idx / cv;
+  const int c = (int)(idx - m * cv) * 8;
+  float o[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const floatx4 g = *reinterpret_cast<const floatx4*>(dy + m * ldy + c + 4 * h);
+    const floatx4 r = *reinterpret_cast<const floatx4*>(ref + m * ldr + c + 4 * h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[4 * h + i] = alpha * g[i] * act_grad(r[i], act, slope, from_output);
+  }
+  ffsr_store_planes8(o_hi + m * ldp + c, o_lo + m * ldp + c, o);
+}
+
 // out = alpha * (sa ? sa[0] : 1) * a + beta * (sb ? sb[0] : 1) * b   (b optional; sa / sb = learnable device scalars)
 __global__ void axpby_dev_kernel(const float* __restrict__ a, int lda, const float* __restrict__ sa, float alpha,
                                  const float* __restrict__ b, int ldb, const float* __restrict__ sb, float beta,
@@ -717,6 +738,16 @@ extern "C" int ffsr_act_bwd_f32(const float* dy, int ldy, const float* ref, int 
   else
     FFSR_LAUNCH(act_bwd_kernel<1>, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, ref, ldr, dx, ldx, M, C, act, slope,
                 from_output, alpha, accumulate);
+  return ffsr_launch_status();
+}
+
+extern "C" int ffsr_act_bwd_planes_f32(const float* dy, int ldy, const float* ref, int ldr, void* out_hi, void* out_lo, int ldp,
+                                       long long M, int C, int act, float slope, int from_output, float alpha, void* stream) {
+  FFSR_CHECK(dy && ref && out_hi && out_lo && M > 0 && C > 0 && (C & 31) == 0 && ldp == C && ldy >= C && ldr >= C && act >= 0 && act <= 7);
+  FFSR_CHECK(!from_output || act == FFSR_ACT_RELU || act == FFSR_ACT_LRELU || act == FFSR_ACT_SIGMOID || act == FFSR_ACT_NONE);
+  FFSR_CHECK(ldy % 4 == 0 && ldr % 4 == 0 && (((uintptr_t)dy | (uintptr_t)ref | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0);
+  FFSR_LAUNCH(act_bwd_planes_kernel, dim3(grid_for(M * (C / 8))), dim3(RB), 0, ST, dy, ldy, ref, ldr, (unsigned short*)out_hi,
+              (unsigned short*)out_lo, ldp, M, C, act, slope, from_output, alpha);
   return ffsr_launch_status();
 }
 

@@ -28,6 +28,9 @@ struct WgradArgs {
   const unsigned short* x_hi;   // X as bf16 hi / lo planes [pixels][ldp] instead of x (conv_wgrad3_bf16x3_kernel<.., XPL = true> only)
   const unsigned short* x_lo;
   int ldp;
+  const unsigned short* dy_hi;  // dY as planes [pixels][ldq] instead of dy (<.., YPL = true>)
+  const unsigned short* dy_lo;
+  int ldq;
   const float* dy;
   float* part;
   float* bias_part;     // [splits][N] column sums of dY (bias gradient) or null
@@ -478,7 +481,8 @@ __device__ __forceinline__ wg_short4 wg_tr_read(const unsigned char* base, unsig
 // EDGE: N / Cin are not multiples of the tile (76 -> 64, 96 -> 32 at HR): channels past the edge are staged as zeros and the
 // waves / fragments that hold nothing but padding skip their reads and MFMAs.
 // XPL: X arrives as bf16 hi / lo planes (the layer's forward input as the planes GEMM consumed it): its rows go to LDS as they are.
-template <int KC, bool EDGE, bool XPL>
+// YPL: dY arrives as planes too (ffsr_act_bwd_planes_f32): nothing is converted in this kernel any more.
+template <int KC, bool EDGE, bool XPL, bool YPL>
 __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   typedef unsigned long long mask_t;
   constexpr int TN = 128, TC = 128, KB = KC + 2, NT = 512;
@@ -555,7 +559,13 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
   auto fetch_piece = [&](int i) {                      // of chunk "2"; pieces 0 .. LA-1: dY rows, LA .. NP-1: X strip rows
     if (i < LA) {
       const long long g = q02 + rowt + RPT * i;
-      ra[i] = *reinterpret_cast<const floatx4*>(p.dy + (g < p.P ? g : p.P - 1) * p.ldy + (n_ok ? n0 + 4 * u : 0));
+      if constexpr (YPL) {
+        const size_t o = (size_t)(g < p.P ? g : p.P - 1) * p.ldq + (n_ok ? n0 + 4 * u : 0);
+        const wg_uint2 h = *reinterpret_cast<const wg_uint2*>(p.dy_hi + o), l2 = *reinterpret_cast<const wg_uint2*>(p.dy_lo + o);
+        ra[i] = __builtin_bit_cast(floatx4, wg_uint4{h[0], h[1], l2[0], l2[1]});
+      } else {
+        ra[i] = *reinterpret_cast<const floatx4*>(p.dy + (g < p.P ? g : p.P - 1) * p.ldy + (n_ok ? n0 + 4 * u : 0));
+      }
     } else if (i < NP) {
       long long g = q02 + shift + rowt + RPT * (i - LA);      // any in-range pixel may be read: invalid taps read the row of zeros
       g = g < 0 ? 0 : (g < p.P ? g : p.P - 1);
@@ -580,8 +590,22 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
     unsigned char* base = wg_smem + buf * STAGE;
     if (i < LA) {
       const floatx4 v = (((ma1 >> (rowt + RPT * i)) & 1) && n_ok) ? ra[i] : zero4;
-      if (do_bias) bsum += v;
-      put(base, base + A_PLANE, rowt + RPT * i, v);
+      if constexpr (YPL) {
+        const wg_uint4 w = __builtin_bit_cast(wg_uint4, v);      // (hi pair 0, hi pair 1, lo pair 0, lo pair 1)
+        if (do_bias) {                                            // (block-uniform) the bias gradient wants the values back: hi + lo
+          const floatx4 hv = {__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                              __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+          const floatx4 lv = {__builtin_bit_cast(float, w[2] << 16), __builtin_bit_cast(float, w[2] & 0xffff0000u),
+                              __builtin_bit_cast(float, w[3] << 16), __builtin_bit_cast(float, w[3] & 0xffff0000u)};
+          bsum += hv + lv;
+        }
+        const unsigned o = wg_img_off(rowt + RPT * i, (int)uoff_chunk) + uoff_half;
+        *reinterpret_cast<wg_uint2*>(base + o) = wg_uint2{w[0], w[1]};
+        *reinterpret_cast<wg_uint2*>(base + A_PLANE + o) = wg_uint2{w[2], w[3]};
+      } else {
+        if (do_bias) bsum += v;
+        put(base, base + A_PLANE, rowt + RPT * i, v);
+      }
     } else if (i < NP) {
       const int j = rowt + RPT * (i - LA);
       const long long g = q01 + shift + j;
@@ -1066,12 +1090,20 @@ static int wgrad_thin(const float* x, int ldx, const float* dy, int ldy, float* 
 
 static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* partial,
                       long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w,
-                      bool split_bf16, void* stream, const void* x_hi = nullptr, const void* x_lo = nullptr, int ldp = 0) {
-  const bool xpl = x_hi != nullptr;
+                      bool split_bf16, void* stream, const void* x_hi = nullptr, const void* x_lo = nullptr, int ldp = 0,
+                      const void* dy_hi = nullptr, const void* dy_lo = nullptr, int ldq = 0) {
+  const bool xpl = x_hi != nullptr, ypl = dy_hi != nullptr;
+  alignas(16) static const float dummy_v[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* const dummy = dummy_v;
+  if (ypl) {
+    FFSR_CHECK(xpl && dy_lo && !dy && (ldq & 31) == 0 && ldq >= N &&
+               ((reinterpret_cast<uintptr_t>(dy_hi) | reinterpret_cast<uintptr_t>(dy_lo)) & 15) == 0);
+    dy = dummy, ldy = N;     // (placeholders for the shared checks: the planes kernel never reads dy)
+  }
   if (xpl) {
     FFSR_CHECK(x_lo && !x && (ldp & 31) == 0 && ldp >= Cin && split_bf16 &&
                ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo)) & 15) == 0);
-    x = dy, ldx = Cin;        // (placeholders for the shared checks below: the planes kernel never reads x)
+    x = dummy, ldx = Cin;        // (placeholders for the shared checks below: the planes kernel never reads x)
   }
   FFSR_CHECK(x && dy && dw && partial && B > 0 && H > 0 && W > 0 && Cin > 0 && N > 0 && KH > 0 && KW > 0 && ldx >= Cin && ldy >= N);
   FFSR_CHECK(pad_h >= 0 && pad_w >= 0 && pad_h < KH && pad_w < KW && (long long)B * H * W < (1ll << 31) - 64);
@@ -1084,6 +1116,7 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   }
   WgradArgs a;
   a.x_hi = (const unsigned short*)x_hi, a.x_lo = (const unsigned short*)x_lo, a.ldp = ldp;
+  a.dy_hi = (const unsigned short*)dy_hi, a.dy_lo = (const unsigned short*)dy_lo, a.ldq = ldq;
   a.x = x, a.dy = dy, a.part = partial, a.bias_part = nullptr, a.ldx = ldx, a.ldy = ldy;
   a.B = B, a.H = H, a.W = W, a.Cin = Cin, a.N = N, a.KH = KH, a.KW = KW, a.ph = pad_h, a.pw = pad_w;
   a.P = (long long)B * H * W;
@@ -1135,18 +1168,21 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
     constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 128;   // two stages + the 4 x 4 chunk masks
     static bool attr_set = false;
     if (!attr_set) {
-      const void* fns[4] = {reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, false>),
-                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, false>),
-                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, true>),
-                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, true>)};
+      const void* fns[6] = {reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, false, false>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, false, false>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, true, false>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, true, false>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, true, true>),
+                            reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, true, true>)};
       for (const void* fn : fns)
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return FFSR_ELAUNCH;
       attr_set = true;
     }
-    if (wide_full && !xpl) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, false, false>), grid, dim3(512), LDS, st, a);
-    else if (!xpl) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, true, false>), grid, dim3(512), LDS, st, a);
-    else if (wide_full) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, false, true>), grid, dim3(512), LDS, st, a);
-    else FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, true, true>), grid, dim3(512), LDS, st, a);
+#define FFSR_WG(E, X, Y) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, E, X, Y>), grid, dim3(512), LDS, st, a)
+    if (ypl) { if (wide_full) FFSR_WG(false, true, true); else FFSR_WG(true, true, true); }
+    else if (xpl) { if (wide_full) FFSR_WG(false, true, false); else FFSR_WG(true, true, false); }
+    else { if (wide_full) FFSR_WG(false, false, false); else FFSR_WG(true, false, false); }
+#undef FFSR_WG
   } else if (row3) {
     if (tn == 32 && tc == 32) FFSR_LAUNCH((conv_wgrad3_kernel<1, 1, 64>), grid, dim3(256), 0, st, a);
     else if (tn == 32 && tc == 64) FFSR_LAUNCH((conv_wgrad3_kernel<1, 2, 16>), grid, dim3(256), 0, st, a);
@@ -1187,10 +1223,11 @@ extern "C" int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, 
 // ffsr_conv_wgrad_bf16x3 with X given as the bf16 hi / lo planes [B*H*W, ldp] the planes GEMM consumed in the forward pass (ldp % 32
 // == 0, pad channels zero): the rows go to LDS as they are, no fp32 copy of the activation has to exist.  Only the shapes the
 // bf16 kernel takes (3-wide, N and Cin multiples of 4, one of them > 64, both >= 32, >= 65536 pixels unless multiples of 128);
-// FFSR_EINVAL otherwise.
-extern "C" int ffsr_conv_wgrad_bf16x3_planes(const void* x_hi, const void* x_lo, int ldp, const float* dy, int ldy, float* dw,
-                                             float* dbias, float* partial, long long partial_floats, int B, int H, int W, int Cin,
-                                             int N, int KH, int KW, int pad_h, int pad_w, void* stream) {
+// FFSR_EINVAL otherwise.  dY: the fp32 map dy, or (dy NULL) the planes dy_hi / dy_lo [B*H*W, ldq] of ffsr_act_bwd_planes_f32.
+extern "C" int ffsr_conv_wgrad_bf16x3_planes(const void* x_hi, const void* x_lo, int ldp, const float* dy, int ldy, const void* dy_hi,
+                                             const void* dy_lo, int ldq, float* dw, float* dbias, float* partial,
+                                             long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h,
+                                             int pad_w, void* stream) {
   return wgrad_impl(nullptr, 0, dy, ldy, dw, dbias, partial, partial_floats, B, H, W, Cin, N, KH, KW, pad_h, pad_w, true, stream,
-                    x_hi, x_lo, ldp);
+                    x_hi, x_lo, ldp, dy_hi, dy_lo, ldq);
 }

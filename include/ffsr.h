@@ -308,10 +308,11 @@ int ffsr_conv_wgrad_bf16x3(const float* x, int ldx, const float* dy, int ldy, fl
                            void* stream);
 /* ffsr_conv_wgrad_bf16x3 with X given as the bf16 hi / lo planes [B*H*W, ldp] that ffsr_conv2d_planes consumed in the forward
  * pass (ldp % 32 == 0, pad channels zero): no fp32 copy of the activation has to exist (the refine stack's GELU outputs,
- * enhanced_fusion_v2.py:569-576, live as planes only).  Shapes: the ones the bf16 kernel takes (see above); FFSR_EINVAL else. */
-int ffsr_conv_wgrad_bf16x3_planes(const void* x_hi, const void* x_lo, int ldp, const float* dy, int ldy, float* dw, float* dbias,
-                                  float* partial, long long partial_floats, int B, int H, int W, int Cin, int N, int KH, int KW,
-                                  int pad_h, int pad_w, void* stream);
+ * enhanced_fusion_v2.py:569-576, live as planes only).  dY: the fp32 map dy, or (dy NULL) the planes dy_hi / dy_lo [B*H*W, ldq]
+ * written by ffsr_act_bwd_planes_f32.  Shapes: the ones the bf16 kernel takes (see above); FFSR_EINVAL else. */
+int ffsr_conv_wgrad_bf16x3_planes(const void* x_hi, const void* x_lo, int ldp, const float* dy, int ldy, const void* dy_hi,
+                                  const void* dy_lo, int ldq, float* dw, float* dbias, float* partial, long long partial_floats,
+                                  int B, int H, int W, int Cin, int N, int KH, int KW, int pad_h, int pad_w, void* stream);
 /* Depthwise (groups = C) weight gradient for the kernel shapes 5x5, 1x21, 21x1 (large_kernel_attention.py:58-76) and 3x3.
  * partial: nchunk * KH*KW * C floats. */
 int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* partial, int nchunk, int B, int H,
@@ -323,6 +324,10 @@ int ffsr_dwconv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, flo
  * (multi_domain_frequency.py:374). */
 int ffsr_act_bwd_f32(const float* dy, int ldy, const float* ref, int ldr, float* dx, int ldx, long long M, int C, int act,
                      float slope, int from_output, float alpha, int accumulate, void* stream);
+/* The same (no accumulation) with the result written as bf16 hi / lo planes [M, ldp] (C % 32 == 0, ldp == C): the gradient
+ * entering a wide layer goes to ffsr_conv2d_planes (input gradient) and ffsr_conv_wgrad_bf16x3_planes without an fp32 copy. */
+int ffsr_act_bwd_planes_f32(const float* dy, int ldy, const float* ref, int ldr, void* out_hi, void* out_lo, int ldp, long long M,
+                            int C, int act, float slope, int from_output, float alpha, void* stream);
 /* out = alpha * sa[0] * a + beta * sb[0] * b  (sa / sb: learnable DEVICE scalars or NULL = 1; b optional): the residual
  * scalings scale1 / scale2 (large_kernel_attention.py:143-148), residual_weight_*, ResBlock.scale, edge_strength,
  * residual_scale, the band scales of multi_domain_frequency.py:192-194,297,385 -- read on the device, no host sync. */

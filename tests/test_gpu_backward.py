@@ -162,22 +162,43 @@ def test_wgrad_from_planes_matches_fp32_input(B, H, W, Cin, N):
     xp = ops.split_planes(xm)
     st = torch.cuda.current_stream().cuda_stream
     outs = []
-    for planes in (False, True):
+    dp = ops.split_planes(dm) if N % 32 == 0 else None
+    for planes in (0, 1, 2):
+        if planes == 2 and dp is None:
+            continue
         dw, db = torch.zeros(N, Cin, 3, 3, device=DEV), torch.zeros(N, device=DEV)
         part = torch.empty(1 << 24, device=DEV)
-        if planes:
-            hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, dm.data_ptr(), dm.stride(2),
+        if planes == 2:        # dY as planes too (what ffsr_act_bwd_planes_f32 writes)
+            hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, None, 0, dp.hi.data_ptr(),
+                     dp.lo.data_ptr(), dp.Cp, dw.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, st)
+        elif planes == 1:
+            hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, dm.data_ptr(), dm.stride(2), None, None, 0,
                      dw.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, st)
         else:
             hip.call("ffsr_conv_wgrad_bf16x3", xm.data_ptr(), xm.stride(2), dm.data_ptr(), dm.stride(2), dw.data_ptr(),
                      db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, st)
         outs.append((dw.cpu(), db.cpu()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:         # weights: the same staged bits -> bit-identical; bias: hi + lo of dY instead of dY (2^-17 relative)
+        assert torch.equal(outs[0][0], o[0]) and rel(o[1], outs[0][1]) < 1e-5
     want = torch.nn.grad.conv2d_weight(x.double(), (N, Cin, 3, 3), dy.double(), padding=1)
     assert rel(outs[1][0].double(), want) < 3e-5
     with pytest.raises(Exception):      # 1x1: no bf16 weight-gradient kernel
-        hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, dm.data_ptr(), dm.stride(2),
+        hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, dm.data_ptr(), dm.stride(2), None, None, 0,
                  dw.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), B, H, W, Cin, N, 1, 1, 0, 0, st)
+
+@pytest.mark.parametrize("act,from_out", [(1, False), (2, True), (3, True)])
+def test_act_bwd_planes_is_split_of_act_bwd(act, from_out):
+    """ffsr_act_bwd_planes_f32 writes split(dy * act'(ref)) -- bit-identical to splitting ffsr_act_bwd_f32's fp32 result."""
+    hip, ops, A = mod("hip"), mod("ops"), mod("autograd")
+    g = gen(act)
+    M, C = 5000, 128
+    dy, ref = torch.randn(M, C, generator=g).to(DEV), torch.randn(M, C, generator=g).to(DEV)
+    t = A.Tape(DEV)
+    want = ops.split_planes(ops.as_map(t.act_bwd(dy, ref, act, 0.2, from_output=from_out)))
+    pl = ops.Planes(1, 1, M, C, DEV)
+    hip.call("ffsr_act_bwd_planes_f32", dy.data_ptr(), C, ref.data_ptr(), C, pl.hi.data_ptr(), pl.lo.data_ptr(), pl.Cp, M, C, act, 0.2,
+             int(from_out), 1.0, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(pl.buf, want.buf)
 
 @pytest.mark.parametrize("B,H,W,Cin,N", [(2, 96, 100, 128, 3), (1, 130, 131, 16, 1), (3, 80, 70, 32, 4), (1, 128, 129, 8, 2),
                                          (2, 96, 100, 3, 128), (1, 150, 113, 4, 32), (2, 90, 95, 1, 8), (1, 200, 90, 64, 3)])
