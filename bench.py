@@ -115,7 +115,7 @@ def train_bench(args):
     line = {"metric": f"cached-feature training steps/s (BASELINE config 5: {B} x {w}x{h} LR patches, fusion net fwd + bwd + AdamW)",
             "value": args.steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (conv products as 3-term split-bf16 MFMA; weight gradients on the exact f32 MFMA)",
+            "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (conv products as 3-term split-bf16 MFMA; weight gradients: split-bf16 MFMA for the wide 3x3 layers, exact fp32 elsewhere)",
             "data": "synthetic (seeded cached expert images / features / HR targets; random-init fusion weights)",
             "config": {"workload": f"train_epoch_cached step: forward_with_precomputed(train) + L1 + backward + clip + AdamW + EMA, "
                                    f"batch {B} of {w}x{h} LR patches -> {4 * w}x{4 * h}", "patches_per_step": B,
