@@ -455,8 +455,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradArgs p) {
 // LDS writes, no MFMA) 0.93 ms, everything 1.78 ms = 348 TFLOP/s: on a SIMD the vector work and the MFMAs add up rather than
 // overlap, however finely they are interleaved (sched_group_barrier shapes, one or two waves per SIMD: +-3 %).  What helped:
 // two waves per SIMD with the border masks moved into the read addresses (2.03 -> 1.92), global loads kept in flight a whole
-// iteration ahead (-> 1.78).  The remaining step is the one the forward GEMMs took: operands that arrive as bf16 planes
-// (LDS-DMA, no vector work in the loop).
+// iteration ahead (-> 1.78).  Operands that arrive as bf16 planes (XPL / YPL below) remove the conversion work and change
+// nothing (1.83 fp32 in, 1.93 planes in: two 256-byte rows per pixel instead of one 512-byte row); a variant of the planes
+// kernel staged by LDS-DMA (swizzle applied on the global side, no vector work, no staging registers; results bit-identical)
+// ran at 2.06 ms and was dropped: the loop is bound by how the three kernel-row workgroups of a pixel range share their rows
+// through L2 / how the 8 waves meet at the per-chunk barrier, not by instruction issue.
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {

@@ -30,5 +30,22 @@ for (B, H, W, Cin, N) in [(32, 256, 256, 128, 128), (32, 64, 64, 128, 128), (8, 
         torch.cuda.synchronize()
         us = (time.time() - t0) / 5 * 1e6
         print(f"{name} B{B} {H}x{W} {Cin}->{N}: {us:.0f} us = {2.0 * B * H * W * Cin * N * 9 / us / 1e6:.1f} TFLOP/s", flush=True)
+    if Cin % 128 == 0 and N % 128 == 0:      # both operands as planes (LDS-DMA staged kernel; FFSR_WGRAD_DMA=0: register staged)
+        ops = importlib.import_module("image-super-resolution_amd.ops")
+        xp, dp = ops.split_planes(x), ops.split_planes(dy)
+        def runp():
+            dw = torch.zeros(N, Cin, 3, 3, device=dev)
+            hip.call("ffsr_conv_wgrad_bf16x3_planes", xp.hi.data_ptr(), xp.lo.data_ptr(), xp.Cp, None, 0, dp.hi.data_ptr(), dp.lo.data_ptr(),
+                     dp.Cp, dw.data_ptr(), None, part.data_ptr(), part.numel(), B, H, W, Cin, N, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream)
+            return dw
+        rp = runp()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            runp()
+        torch.cuda.synchronize()
+        us = (time.time() - t0) / 5 * 1e6
+        print(f"planes x planes B{B} {H}x{W} {Cin}->{N}: {us:.0f} us = {2.0 * B * H * W * Cin * N * 9 / us / 1e6:.1f} TFLOP/s; "
+              f"equal to fp32-input bf16x3: {torch.equal(rp, res['ffsr_conv_wgrad_bf16x3'])}", flush=True)
     a, b = res["ffsr_conv_wgrad_f32"], res["ffsr_conv_wgrad_bf16x3"]
     print("  max rel diff bf16x3 vs f32:", ((a - b).abs().max() / a.abs().max()).item(), flush=True)
