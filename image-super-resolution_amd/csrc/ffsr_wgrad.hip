@@ -458,8 +458,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradArgs p) {
 // iteration ahead (-> 1.78).  Operands that arrive as bf16 planes (XPL / YPL below) remove the conversion work and change
 // nothing (1.83 fp32 in, 1.93 planes in: two 256-byte rows per pixel instead of one 512-byte row); a variant of the planes
 // kernel staged by LDS-DMA (swizzle applied on the global side, no vector work, no staging registers; results bit-identical)
-// ran at 2.06 ms and was dropped: the loop is bound by how the three kernel-row workgroups of a pixel range share their rows
-// through L2 / how the 8 waves meet at the per-chunk barrier, not by instruction issue.
+// ran at 2.06 ms and was dropped.  One kernel row (1x3) takes exactly a third of the 3x3 time (tools/probe/wgrad_kh1.py): no
+// loss to row sharing between workgroups either -- what is left is the workgroup's own pipeline (fragment-read latency at two
+// waves per SIMD, the per-chunk barrier of 8 waves).
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
