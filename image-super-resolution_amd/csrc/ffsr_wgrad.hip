@@ -706,6 +706,18 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
       const unsigned char* Alo = Ahi + A_PLANE;
       const unsigned char* Bhi = Ahi + 2 * A_PLANE;
       const unsigned char* Blo = Bhi + B_PLANE;
+      // X fragments are read one (step, tap) slot ahead into the other of two register sets: the slot's MFMAs cover their LDS latency
+      wg_bf16x8 bh[2], bl[2];
+      auto read_b = [&](int set, int s, int kx) {
+        unsigned ob[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {      // bit 16 s + 4 rr + krow of the tap's mask: the pixel of the row this lane addresses
+          const unsigned m = (unsigned)(mk[kx] >> (16 * s + 4 * rr));
+          ob[rr] = zoff + ((0u - ((m >> krow) & 1u)) & (dB[kx][rr] + 4096u * s));
+        }
+        bh[set] = frag(Bhi, ob), bl[set] = frag(Blo, ob);
+      };
+      if (act_n[0]) read_b(0, 0, 0);
       static_for<0, KC / 16>([&](auto s_tag) {
         constexpr int s = decltype(s_tag)::value;
         wg_bf16x8 ah[2], al[2];
@@ -719,19 +731,13 @@ __global__ __launch_bounds__(512) void conv_wgrad3_bf16x3_kernel(WgradArgs p) {
         for (int kx = 0; kx < 3; ++kx) {
           const int slot = 3 * s + kx;
           if (act_n[0]) {                    // (wave-uniform; always true without EDGE)
-            unsigned ob[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {      // bit 16 s + 4 rr + krow of the tap's mask: the pixel of the row this lane addresses
-              const unsigned m = (unsigned)(mk[kx] >> (16 * s + 4 * rr));
-              ob[rr] = zoff + ((0u - ((m >> krow) & 1u)) & (dB[kx][rr] + 4096u * s));
-            }
-            const wg_bf16x8 bh = frag(Bhi, ob), bl = frag(Blo, ob);
+            if (slot + 1 < SLOTS) read_b((slot + 1) & 1, (slot + 1) / 3, (slot + 1) % 3);
 #pragma unroll
             for (int fn = 0; fn < 2; ++fn)
               if (act_n[fn]) {
-                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fn], bh, acc[kx][fn], 0, 0, 0);
-                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bl, acc[kx][fn], 0, 0, 0);
-                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bh, acc[kx][fn], 0, 0, 0);
+                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fn], bh[slot & 1], acc[kx][fn], 0, 0, 0);
+                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bl[slot & 1], acc[kx][fn], 0, 0, 0);
+                acc[kx][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fn], bh[slot & 1], acc[kx][fn], 0, 0, 0);
               }
           }
 #pragma unroll
