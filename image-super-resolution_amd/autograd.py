@@ -107,6 +107,13 @@ class BnP:
         self.calls = 0                      # num_batches_tracked
 
 
+def _wgrad_scratch(p) -> int:
+    """floats of scratch for a layer's weight gradient: room for 256 pixel splits of the MFMA kernels, and for the 1024 block
+    partials of the thin-layer kernels (N <= 4 or Cin <= 4: small tiles -- with 256 they ran on a quarter of the chip)"""
+    per = p.weight.v.numel() + p.N
+    return max(per * 256, min(per * 1024, 1 << 23), 1 << 20)
+
+
 def conv_tile(M: int, N: int, taps: int, cin: int = 0) -> int:
     """explicit tile_hint of ops.conv2d for fp32-map inputs: the split-bf16 kernel where the default mode would take it,
     else the exact f32 kernel (also FFSR_GEMM_MODE=f32).  0 = ops.conv2d's own choice: for the wide k x k layers at HR (the refine
@@ -250,7 +257,7 @@ class Tape:
                 gz = _zero_padded(gy, p.N, self.device)  # the dgrad GEMM contracts over pad4(N) aligned channels: pad = 0
             else:
                 gz = gy
-            part = torch.empty(max((p.weight.v.numel() + p.N) * 256, 1 << 20), device=self.device)   # room for up to 256 pixel splits
+            part = torch.empty(_wgrad_scratch(p), device=self.device)
             hip.call("ffsr_conv_wgrad_bf16x3" if ops.GEMM_MODE == "bf16x3" and WGRAD_BF16X3 else "ffsr_conv_wgrad_f32", _ptr(xm), ops.ld(xm), _ptr(gz), ops.ld(gz), _ptr(p.weight.g),
                      None if p.bias is None else _ptr(p.bias.g), _ptr(part),
                      part.numel(), B, H, W, p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
@@ -315,7 +322,7 @@ class Tape:
                 _, Mr, C, ldg = _mat(gy)
                 hip.call("ffsr_act_bwd_planes_f32", _ptr(gy), ldg, _ptr(zs[k]), _mat(zs[k])[3], _ptr(gz.hi), _ptr(gz.lo), gz.Cp, Mr, C,
                          ACT_GELU, 0.0, 0, 1.0, _stream())
-                part = torch.empty(max((p.weight.v.numel() + p.N) * 256, 1 << 20), device=self.device)
+                part = torch.empty(_wgrad_scratch(p), device=self.device)
                 hip.call("ffsr_conv_wgrad_bf16x3_planes", _ptr(ins[k].hi), _ptr(ins[k].lo), ins[k].Cp, None, 0, _ptr(gz.hi), _ptr(gz.lo),
                          gz.Cp, _ptr(p.weight.g), None if p.bias is None else _ptr(p.bias.g), _ptr(part), part.numel(), B, H, W,
                          p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
