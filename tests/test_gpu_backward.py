@@ -285,7 +285,7 @@ def test_layernorm_backward(M, C):
 
 # ---------------------------------------------------------------------------------------------- resamplers
 @pytest.mark.parametrize("Hi,Wi,Ho,Wo,C", [(16, 16, 64, 64, 32), (64, 64, 16, 16, 12), (64, 64, 32, 32, 12), (35, 51, 140, 204, 3),
-                                           (64, 64, 32, 17, 1), (17, 13, 40, 29, 4), (8, 8, 1, 1, 3)])
+                                           (64, 64, 32, 17, 1), (17, 13, 40, 29, 4), (8, 8, 1, 1, 3), (33, 47, 132, 188, 128), (20, 30, 50, 45, 8)])
 def test_bilinear_adjoint(Hi, Wi, Ho, Wo, C):
     A = mod("autograd")
     g = gen(Hi + Wo)
