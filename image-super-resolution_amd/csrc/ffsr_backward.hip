@@ -120,16 +120,25 @@ __global__ void act_bwd_planes_kernel(const float* __restrict__ dy, int ldy, con
 }
 
 // out = alpha * (sa ? sa[0] : 1) * a + beta * (sb ? sb[0] : 1) * b   (b optional; sa / sb = learnable device scalars)
+template <int V>
 __global__ void axpby_dev_kernel(const float* __restrict__ a, int lda, const float* __restrict__ sa, float alpha,
                                  const float* __restrict__ b, int ldb, const float* __restrict__ sb, float beta,
                                  float* __restrict__ out, int ldo, long long M, int C) {
+  const int cv = C / V;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * C) return;
-  const long long m = idx / C;
-  const int c = (int)(idx - m * C);
-  float y = alpha * (sa ? sa[0] : 1.f) * a[m * lda + c];
-  if (b) y += beta * (sb ? sb[0] : 1.f) * b[m * ldb + c];
-  out[m * ldo + c] = y;
+  if (idx >= M * cv) return;
+  const long long m = idx / cv;
+  const int c = (int)(idx - m * cv) * V;
+  const float fa = alpha * (sa ? sa[0] : 1.f), fb = beta * (sb ? sb[0] : 1.f);
+  if constexpr (V == 4) {
+    floatx4 y = *reinterpret_cast<const floatx4*>(a + m * lda + c) * fa;
+    if (b) y += *reinterpret_cast<const floatx4*>(b + m * ldb + c) * fb;
+    *reinterpret_cast<floatx4*>(out + m * ldo + c) = y;
+  } else {
+    float y = fa * a[m * lda + c];
+    if (b) y += fb * b[m * ldb + c];
+    out[m * ldo + c] = y;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- reductions
@@ -793,7 +802,11 @@ extern "C" int ffsr_act_bwd_planes_f32(const float* dy, int ldy, const float* re
 extern "C" int ffsr_axpby_dev_f32(const float* a, int lda, const float* sa, float alpha, const float* b, int ldb,
                                   const float* sb, float beta, float* out, int ldo, long long M, int C, void* stream) {
   FFSR_CHECK(a && out && M > 0 && C > 0 && lda >= C && ldo >= C && (!b || ldb >= C));
-  FFSR_LAUNCH(axpby_dev_kernel, dim3(grid_for(M * C)), dim3(RB), 0, ST, a, lda, sa, alpha, b, ldb, sb, beta, out, ldo, M, C);
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (C % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && (!b || ldb % 4 == 0) && al16(a) && al16(out) && (!b || al16(b)))
+    FFSR_LAUNCH(axpby_dev_kernel<4>, dim3(grid_for(M * (C / 4))), dim3(RB), 0, ST, a, lda, sa, alpha, b, ldb, sb, beta, out, ldo, M, C);
+  else
+    FFSR_LAUNCH(axpby_dev_kernel<1>, dim3(grid_for(M * C)), dim3(RB), 0, ST, a, lda, sa, alpha, b, ldb, sb, beta, out, ldo, M, C);
   return ffsr_launch_status();
 }
 
