@@ -156,6 +156,42 @@ def train_bench(args):
     print(json.dumps(line))
 
 
+def dry_run(args):
+    """The multi-rank plumbing of the bench without the engine: rendezvous, weight broadcast (rank 0's values must reach
+    every rank), barrier-bracketed timed region, MAX over ranks, one JSON line from rank 0.  CPU / gloo; marked dry_run."""
+    W = importlib.import_module("image-super-resolution_amd.weights")
+    S = importlib.import_module("image-super-resolution_amd.shard")
+    rank, world = S.rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    S.init_process_group(args.backend)
+    weights = {"fusion": W.fusion_state_dict(seed=5)} if rank == 0 else None
+    templ = {"fusion": {k: torch.empty(v.shape, device="meta") for k, v in W.fusion_state_dict(seed=5).items()}}
+    weights = S.broadcast_weights(weights if rank == 0 else templ, torch.device("cpu"))
+    check = float(sum(v.double().sum() for v in weights["fusion"].values() if v.is_floating_point()))
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))            # the slowest rank sets the time
+    if world > 1:
+        torch.distributed.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    sums = torch.tensor([check], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        torch.distributed.all_gather(gathered, sums)
+        assert all(float(g) == check for g in gathered), "broadcast weights differ between ranks"
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launch / rendezvous / broadcast plumbing only)", "dry_run": True, "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * float(tmax) / max(args.steps, 1), "weights_checksum": check}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["infer", "train"], default="infer",
@@ -172,9 +208,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=None, help="GEMM arithmetic (default: the engine's default)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / broadcast / timing plumbing only, no engine and no GPU (CPU tests; not a bench)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher -- it starts N fresh rank processes (one
+        # per GPU, the reference's scheme: scripts/kaggle_inference_fixed.py:385-397), relays rank 0's JSON line and exits
+        # with their status.  It never touches a GPU itself and is never replaced by another program.
+        S = importlib.import_module("image-super-resolution_amd.shard")
+        def relay(rank, line, is_err):       # stdout carries rank 0's JSON line and nothing else (gloo chats on stdout)
+            out = sys.stdout if (rank == 0 and not is_err and line.lstrip().startswith("{")) else sys.stderr
+            out.write(line)
+            out.flush()
+
+        procs, threads, _ = S.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], relay=relay)
+        sys.exit(S.join_ranks(procs, threads))
     if args.config == "train":
         return train_bench(args)
+    if args.dry_run:
+        return dry_run(args)
 
     W = importlib.import_module("image-super-resolution_amd.weights")
     E = importlib.import_module("image-super-resolution_amd.engine")

@@ -235,7 +235,7 @@ class Tape:
         xm = ops.as_map(xv) if is2d else xv
         B, H, W, _ = xm.shape
         M = B * H * W
-        hint = 0 if ops.thin3_ok(p.fwd, M) else conv_tile(M, p.N, p.KH * p.KW, p.Cin)   # (0: the N <= 4 heads take the streaming kernel)
+        hint = 0 if ops.thin3_ok(p.fwd, M, xm) else conv_tile(M, p.N, p.KH * p.KW, p.Cin)   # (0: the N <= 4 heads take the streaming kernel)
         fused = act if act in (ACT_RELU, ACT_LRELU, ACT_SIGMOID) else ACT_NONE
         om = None if out is None else (ops.as_map(out) if out.dim() == 2 else out)
         if act == ACT_GELU:
@@ -262,8 +262,9 @@ class Tape:
                      None if p.bias is None else _ptr(p.bias.g), _ptr(part),
                      part.numel(), B, H, W, p.Cin, p.N, p.KH, p.KW, p.pad, p.pad, _stream())
             if x.req:
-                gx = ops.conv2d(ops.widen(gz, p.bwd.Cin), p.bwd,
-                                tile_hint=0 if ops.thin3_ok(p.bwd, M) else conv_tile(M, p.Cin, p.KH * p.KW, p.N))
+                gzw = ops.widen(gz, p.bwd.Cin)
+                gx = ops.conv2d(gzw, p.bwd,
+                                tile_hint=0 if ops.thin3_ok(p.bwd, M, gzw) else conv_tile(M, p.Cin, p.KH * p.KW, p.N))
                 self.acc(x, _unmap(gx) if is2d else gx)
         self._rec(bw)
         return y

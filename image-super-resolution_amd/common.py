@@ -35,7 +35,7 @@ class SRTail:
         self.up0 = ops.pack_conv(sd[up_prefix + "0.weight"], sd[up_prefix + "0.bias"], device)
         self.up2 = ops.pack_conv(sd[up_prefix + "2.weight"], sd[up_prefix + "2.bias"], device)
         mean = torch.tensor(RGB_MEAN)
-        self.last = ops.pack_conv(sd["conv_last.weight"], sd["conv_last.bias"].float() + mean, device)
+        self.last = ops.pack_conv(sd["conv_last.weight"], sd["conv_last.bias"].float() + mean.to(sd["conv_last.bias"].device), device)
         self.neg_mean = dev(-mean, device)
 
     def center(self, lr):

@@ -178,10 +178,13 @@ __global__ __launch_bounds__(RB) void dot_finish_kernel(const double* __restrict
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)(scale * t);
 }
 
-// column reductions: part[chunk, c] = sum over the rows of the chunk of a[m, c] * (b ? b[m, c] : 1)
-// grid (ceil(C / 64), nchunk), block 256 = 64 channels x 4 row lanes
+// column reductions: part[chunk, c] = sum over the rows of the chunk of a'[m, c] * (b ? b'[m, c] : 1) with
+// b' = b - shift[c] * shift_scale (shift_mode >= 1) and a' = a - shift[c] * shift_scale (shift_mode == 2): CENTRED second
+// moments (BatchNorm's variance and dgamma are sums around the batch mean; E[x^2] - mu^2 from fp32 sums cancels when
+// |mean| >> std).  grid (ceil(C / 64), nchunk), block 256 = 64 channels x 4 row lanes
 __global__ __launch_bounds__(RB) void coldot_partial_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
-                                                            int ldb, long long M, int C, int nchunk, float* __restrict__ part) {
+                                                            int ldb, long long M, int C, int nchunk, float* __restrict__ part,
+                                                            const float* __restrict__ shift, float shift_scale, int shift_mode) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -189,12 +192,14 @@ __global__ __launch_bounds__(RB) void coldot_partial_kernel(const float* __restr
   const long long r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
+    const float sb = shift_mode >= 1 ? shift[c] * shift_scale : 0.f;
+    const float sa = shift_mode == 2 ? sb : 0.f;
     long long r = r0 + rl;
     for (; r + 4 < r1; r += 8) {
-      s0 += a[r * lda + c] * (b ? b[r * ldb + c] : 1.f);
-      s1 += a[(r + 4) * lda + c] * (b ? b[(r + 4) * ldb + c] : 1.f);
+      s0 += (a[r * lda + c] - sa) * (b ? b[r * ldb + c] - sb : 1.f);
+      s1 += (a[(r + 4) * lda + c] - sa) * (b ? b[(r + 4) * ldb + c] - sb : 1.f);
     }
-    for (; r < r1; r += 4) s0 += a[r * lda + c] * (b ? b[r * ldb + c] : 1.f);
+    for (; r < r1; r += 4) s0 += (a[r * lda + c] - sa) * (b ? b[r * ldb + c] - sb : 1.f);
   }
   red[rl][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
@@ -258,7 +263,9 @@ __global__ void bn_stats_finish_kernel(const float* __restrict__ sums, long long
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mu = (double)sums[c] / (double)M;
-  double var = (double)sums[C + c] / (double)M - mu * mu;
+  // sums[C + c] = sum (x - m)^2 around m = fp32(sums[c] / M); the exact variance is that minus (mu - m)^2
+  const double dm = mu - (double)(sums[c] * (1.f / (float)M));
+  double var = (double)sums[C + c] / (double)M - dm * dm;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   mean_rstd[c] = (float)mu;
@@ -272,8 +279,8 @@ __global__ void bn_stats_finish_kernel(const float* __restrict__ sums, long long
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
   }
 }
-// sums [2, C] = (sum dy, sum dy * x).  Coefficients of dx = A dy + Bx x + K (per channel) and the parameter gradients:
-//   xhat = (x - mu) rstd,  dgamma = sum dy xhat = rstd (S2 - mu S1),  dbeta = S1,
+// sums [2, C] = (sum dy, sum dy * (x - mu)).  Coefficients of dx = A dy + Bx x + K (per channel) and the parameter gradients:
+//   xhat = (x - mu) rstd,  dgamma = sum dy xhat = rstd S2,  dbeta = S1,
 //   dx = gamma rstd (dy - S1 / M - xhat dgamma / M)
 __global__ void bn_bwd_finish_kernel(const float* __restrict__ sums, long long M, int C, const float* __restrict__ gamma,
                                      const float* __restrict__ mean_rstd, float* __restrict__ coef, float* __restrict__ dgamma,
@@ -281,7 +288,7 @@ __global__ void bn_bwd_finish_kernel(const float* __restrict__ sums, long long M
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double S1 = sums[c], S2 = sums[C + c], mu = mean_rstd[c], rstd = mean_rstd[C + c];
-  const double dg = rstd * (S2 - mu * S1);
+  const double dg = rstd * S2;
   const double g = (double)gamma[c] * rstd;
   const double k = rstd * dg / (double)M;          // dx = g dy - g k (x - mu) - g S1 / M
   coef[c] = (float)g;
@@ -824,7 +831,8 @@ extern "C" int ffsr_dot_acc_f32(const float* a, int lda, const float* b, int ldb
 extern "C" int ffsr_coldot_acc_f32(const float* a, int lda, const float* b, int ldb, long long M, int C, float* part,
                                    int nchunk, float* out, int ostride, float scale, int accumulate, void* stream) {
   FFSR_CHECK(a && part && out && M > 0 && C > 0 && lda >= C && (!b || ldb >= C) && nchunk >= 1 && nchunk <= 65535 && ostride >= 1);
-  FFSR_LAUNCH(coldot_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(RB), 0, ST, a, lda, b, ldb, M, C, nchunk, part);
+  FFSR_LAUNCH(coldot_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(RB), 0, ST, a, lda, b, ldb, M, C, nchunk, part,
+              (const float*)nullptr, 0.f, 0);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, out, ostride, scale, accumulate);
   return ffsr_launch_status();
 }
@@ -850,9 +858,11 @@ extern "C" int ffsr_bn_train_stats_f32(const float* x, int ldx, long long M, int
   FFSR_CHECK(x && gamma && beta && part && sums && stat && scale_shift && M > 0 && C > 0 && ldx >= C && nchunk >= 1 && nchunk <= 65535);
   FFSR_CHECK(!run_mean == !run_var);
   const dim3 g((C + 63) / 64, nchunk);
-  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, (const float*)nullptr, 0, M, C, nchunk, part);
+  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, (const float*)nullptr, 0, M, C, nchunk, part,
+              (const float*)nullptr, 0.f, 0);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
-  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, x, ldx, M, C, nchunk, part);
+  // second pass around the batch mean: sums[C + c] = sum (x - mean)^2 (two-pass variance, as accurate as torch's Welford)
+  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, x, ldx, x, ldx, M, C, nchunk, part, sums, 1.f / (float)M, 2);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
   FFSR_LAUNCH(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, sums, M, C, gamma, beta, eps, momentum, stat,
               scale_shift, run_mean, run_var);
@@ -867,9 +877,11 @@ extern "C" int ffsr_bn_train_bwd_f32(const float* x, int ldx, const float* dy, i
   FFSR_CHECK(x && dy && dx && gamma && stat && part && sums && coef && dgamma && dbeta && M > 0 && C > 0 && ldx >= C &&
              ldy >= C && lddx >= C && nchunk >= 1 && nchunk <= 65535);
   const dim3 g((C + 63) / 64, nchunk);
-  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, (const float*)nullptr, 0, M, C, nchunk, part);
+  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, (const float*)nullptr, 0, M, C, nchunk, part,
+              (const float*)nullptr, 0.f, 0);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums, 1, 1.f, 0);
-  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, x, ldx, M, C, nchunk, part);
+  // sums[C + c] = sum dy (x - mean): dgamma's sum taken around the batch mean (no S2 - mu S1 cancellation)
+  FFSR_LAUNCH(coldot_partial_kernel, g, dim3(RB), 0, ST, dy, ldy, x, ldx, M, C, nchunk, part, stat, 1.f, 1);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 31) / 32), dim3(RB), 0, ST, part, nchunk, C, C, sums + C, 1, 1.f, 0);
   FFSR_LAUNCH(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, sums, M, C, gamma, stat, coef, dgamma, dbeta);
   FFSR_LAUNCH(affine2_kernel, dim3(grid_for(M * C)), dim3(RB), 0, ST, dy, ldy, x, ldx, coef, dx, lddx, M, C);

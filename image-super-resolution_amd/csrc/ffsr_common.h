@@ -34,6 +34,19 @@ static inline int ffsr_launch_status() {
     if (hipGetLastError() != hipSuccess) ffsr_launch_failed() = 1; \
   } while (0)
 
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize set once PER DEVICE (the code
+// object is loaded per device).  `done_mask` = a static per kernel instantiation: bit d = already set on device d.
+static inline int ffsr_allow_dynamic_lds(const void* const* fns, int n, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return FFSR_ELAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return FFSR_OK;
+  for (int i = 0; i < n; ++i)
+    if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return FFSR_ELAUNCH;
+  __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+  return FFSR_OK;
+}
+
 // activation codes shared by the GEMM/conv epilogue, the depthwise conv and the elementwise kernels
 enum FfsrAct : int {
   FFSR_ACT_NONE = 0,

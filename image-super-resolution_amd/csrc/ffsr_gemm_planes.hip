@@ -420,13 +420,9 @@ int launch_planes3(const PlaneArgs& a, hipStream_t st) {
   static_assert(STAGES * STAGE >= (BM / 32) * 32 * 36 * 4, "epilogue scratch");
   static_assert(STAGES * STAGE <= 160 * 1024, "LDS");
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * STAGE) != hipSuccess)
-      return FFSR_ELAUNCH;
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;
+  const void* fn = reinterpret_cast<const void*>(&conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>);
+  if (ffsr_allow_dynamic_lds(&fn, 1, STAGES * STAGE, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
   FFSR_LAUNCH((conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>), dim3(tiles), dim3(BM * 2), STAGES * STAGE, st, a);
   return ffsr_launch_status();
 }
@@ -641,13 +637,9 @@ int launch_strip3(const PlaneArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * (2 * 144 * 64) + 2 * (2 * BN * 64);
   static_assert(LDS >= 4 * 32 * 36 * 4, "epilogue scratch");
   const int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU, SCHED>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return FFSR_ELAUNCH;
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;
+  const void* fn = reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU, SCHED>);
+  if (ffsr_allow_dynamic_lds(&fn, 1, LDS, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
   FFSR_LAUNCH((conv3_strip_planes_kernel<BN, GELU, SCHED>), dim3(tiles), dim3(256), LDS, st, a);
   return ffsr_launch_status();
 }

@@ -1176,17 +1176,15 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int ldy, float* 
   hipStream_t st = (hipStream_t)stream;
   if (wide3) {
     constexpr int KCW = 64, LDS = 2 * (2 * KCW * 256 + 2 * (KCW + 3) * 256) + 128;   // two stages + the 4 x 4 chunk masks
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    {
       const void* fns[6] = {reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, false, false>),
                             reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, false, false>),
                             reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, true, false>),
                             reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, true, false>),
                             reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, false, true, true>),
                             reinterpret_cast<const void*>(&conv_wgrad3_bf16x3_kernel<KCW, true, true, true>)};
-      for (const void* fn : fns)
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return FFSR_ELAUNCH;
-      attr_set = true;
+      if (ffsr_allow_dynamic_lds(fns, 6, LDS, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
     }
 #define FFSR_WG(E, X, Y) FFSR_LAUNCH((conv_wgrad3_bf16x3_kernel<KCW, E, X, Y>), grid, dim3(512), LDS, st, a)
     if (ypl) { if (wide_full) FFSR_WG(false, true, true); else FFSR_WG(true, true, true); }

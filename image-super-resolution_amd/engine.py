@@ -32,10 +32,11 @@ class Engine:
     def __init__(self, weights: Dict[str, dict], device=None, scale=4):
         self.device = require_gpu(device)
         self.scale = scale
-        # weight preparation (packing, BN folding, bias tables) is host code: normalise to CPU fp32 first
-        # (after shard.broadcast_weights the tensors live on the device)
-        weights = {m: {k: v.detach().to(device="cpu", dtype=torch.float32) if v.is_floating_point() else v.cpu()
-                       for k, v in sd.items()} for m, sd in weights.items()}
+        # weight preparation (packing, BN folding, bias tables) runs as torch ops on whatever device the tensors already
+        # live on: after shard.broadcast_weights that is THIS GPU (views of the one broadcast blob), so nothing is staged
+        # back through the host; a state_dict read from disk is on the CPU and is uploaded tensor by tensor while packing
+        weights = {m: {k: (v.detach().float() if v.is_floating_point() else v.detach()) for k, v in sd.items()}
+                   for m, sd in weights.items()}
         with torch.cuda.device(self.device):
             self.drct = DRCT(weights["drct"], self.device)
             self.grl = GRL(weights["grl"], self.device)
@@ -62,6 +63,10 @@ class Engine:
         B, h, w, _ = lr.shape
         s = self.scale
         hp, wp = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+        if with_lr_phases:
+            # input-independent tables of this image size (DFT twiddles, FFT mask) are built on the CALLER's stream, before
+            # the fork: every side stream (and the other lane) orders itself behind `ready` / this stream
+            self.fusion.prepare(h, w)
         lp = ops.pad_reflect(lr, hp, wp)
         imgs, feats = {}, {}
 

@@ -148,18 +148,32 @@ class FusionNet:
         self.edge_strength = dev(g(p + "edge_strength").reshape(1), device)
 
     # ------------------------------------------------------------------------------------------ phase 2
+    def prepare(self, h, w):
+        """Build (once per image size) the cached input-independent tables on the CURRENT stream and make every later user
+        wait for them: the cache entry carries an event that `_fft_tables` makes the consuming stream wait on, so a hit
+        from another stream lane (or from a side stream) can never read a table that is still being written."""
+        self._fft_tables(h, w)
+
     def _fft_tables(self, h, w):
         key = (h, w)
-        if key not in self._fft_cache:
-            def tw(n):
-                j = torch.arange(n, dtype=torch.float64) * (2 * math.pi / n)
-                return torch.stack([torch.cos(j), torch.sin(j)], 1).float().contiguous().to(self.device)
-            wf = w // 2 + 1
-            mask = torch.empty(1, h, wf, 1, device=self.device)
-            ops.bilinear(self.fft_logits, h, wf, out=mask)
-            ops.unary(mask, act=ACT_SIGMOID, pre=self.fft_temp, out=mask)
-            self._fft_cache[key] = (tw(w), tw(h), mask)
-        return self._fft_cache[key]
+        ent = self._fft_cache.get(key)
+        if ent is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(self.device).wait_event(ent[3])
+            return ent[:3]
+
+        def tw(n):
+            j = torch.arange(n, dtype=torch.float64) * (2 * math.pi / n)
+            return torch.stack([torch.cos(j), torch.sin(j)], 1).float().contiguous().to(self.device)
+        wf = w // 2 + 1
+        mask = torch.empty(1, h, wf, 1, device=self.device)
+        ops.bilinear(self.fft_logits, h, wf, out=mask)
+        ops.unary(mask, act=ACT_SIGMOID, pre=self.fft_temp, out=mask)
+        tabs = (tw(w), tw(h), mask)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self._fft_cache[key] = tabs + (done,)
+        return tabs
 
     def frequency_bands(self, lr):
         """lr [B,h,w,3] -> bands [B,h,w,36] = 9 bands x (3 channels + zero pad)."""

@@ -108,6 +108,10 @@ class FusionTrainNet:
         self.co_mha = _MHA(P, p + "cross_attn.", device, 8)
         self.co_f0, self.co_f2 = cp(p + "ffn.0"), cp(p + "ffn.2")
         self.co_lka = _LKA(P, buf, p + "lka_global.", device)
+        # every nn.BatchNorm2d by its state_dict prefix (num_batches_tracked bookkeeping of FusionTrainer.state_dict)
+        self.batchnorms = {}
+        for q, blk in (("cross_band.lka_block.", self.cb_lka), ("collaborative.lka_global.", self.co_lka)):
+            self.batchnorms.update({q + "norm1": blk.n1, q + "norm2": blk.n2, q + "lka.bn": blk.lbn})
         self.mod0 = [cp(f"{p}modulation.{i}.0") for i in range(4)]
         self.mod2 = [cp(f"{p}modulation.{i}.2") for i in range(4)]
         # ---- phase 5

@@ -41,10 +41,11 @@ def _rel_index(ws, aws, window_to_anchor):
 def _cpb_bias_T(sd, p, table, index, device):
     """16 * sigmoid(CPB_MLP(table))[index] as [heads, N_keys, N_queries] (transposed for lane-coalesced reads)
     plus exp(min(logit_scale, ln 100)) per head.  Weight pre-processing (input independent), done on the host."""
-    h = F.relu(F.linear(table.reshape(-1, 2), sd[p + "cpb_mlp.0.weight"].float(), sd[p + "cpb_mlp.0.bias"].float()))
-    tab = F.linear(h, sd[p + "cpb_mlp.2.weight"].float())
+    # (the tables are built on the host: the few KB of CPB-MLP weights come to the CPU wherever the state_dict lives)
+    h = F.relu(F.linear(table.reshape(-1, 2), sd[p + "cpb_mlp.0.weight"].float().cpu(), sd[p + "cpb_mlp.0.bias"].float().cpu()))
+    tab = F.linear(h, sd[p + "cpb_mlp.2.weight"].float().cpu())
     b = 16 * torch.sigmoid(tab[index.reshape(-1)].reshape(index.shape[0], index.shape[1], -1))   # [Nq, Nk, heads]
-    logit = torch.clamp(sd[p + "logit_scale"].float().reshape(-1), max=math.log(100.0)).exp()
+    logit = torch.clamp(sd[p + "logit_scale"].float().cpu().reshape(-1), max=math.log(100.0)).exp()
     return dev(b.permute(2, 1, 0), device), dev(logit, device)
 
 

@@ -273,11 +273,16 @@ PLANES_ACTS = (ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU)
 THIN3 = os.environ.get("FFSR_THIN3", "1") != "0"   # FFSR_THIN3=0: the N <= 4 3x3 heads stay on the GEMM kernels (A/B runs)
 
 
-def thin3_ok(cv: "Conv", M: int) -> bool:
+def thin3_ok(cv: "Conv", M: int, x: Optional[torch.Tensor] = None) -> bool:
     """3x3 / stride 1 / pad 1 with N <= 4 over an fp32 map: ffsr_conv3x3_thin_f32 (a streaming fp32 reduction) instead of a
-    32-column MFMA tile that is 7/8 padding."""
-    return (THIN3 and cv.KH == 3 and cv.KW == 3 and cv.stride == 1 and cv.pad == 1 and cv.N <= 4
-            and cv.Cin in (8, 16, 32, 64, 128) and cv.N <= cv.Cin // 4 and M >= 4096)
+    32-column MFMA tile that is 7/8 padding.  x (the input map, if known): the kernel reads 16-byte vectors, so the pixel
+    stride must be a multiple of 4 and the first pixel 16-byte aligned -- a channel-slice view at an odd offset takes the
+    GEMM kernels instead."""
+    ok = (THIN3 and cv.KH == 3 and cv.KW == 3 and cv.stride == 1 and cv.pad == 1 and cv.N <= 4
+          and cv.Cin in (8, 16, 32, 64, 128) and cv.N <= cv.Cin // 4 and M >= 4096)
+    if ok and x is not None:
+        ok = ld(x) % 4 == 0 and x.data_ptr() % 16 == 0 and ld(x) >= cv.Cin and rows(x) * ld(x) * 4 < 2 ** 32
+    return ok
 PLANES_AUTO = os.environ.get("FFSR_PLANES", "1") != "0"   # FFSR_PLANES=0: every GEMM takes its fp32 input directly
 
 
@@ -302,7 +307,7 @@ def conv2d(x, cv: Conv, *, act=ACT_NONE, slope=0.0, out: Optional[torch.Tensor] 
         oshape = (B, Ho, Wo, cv.N)
     is_planes = isinstance(x, Planes)
     if (not is_planes and not gate and not shuffle and akscale is None and cvec is None and rvec is None and out_planes is None
-            and tile_hint == 0 and thin3_ok(cv, B * Ho * Wo) and ld(x) >= cv.Cin and B * H * W * ld(x) * 4 < 2 ** 32):
+            and tile_hint == 0 and thin3_ok(cv, B * Ho * Wo, x)):
         if out is None:
             out = new_map(*oshape, x.device)
         assert tuple(out.shape) == oshape and (res is None or tuple(res.shape) == oshape)

@@ -102,6 +102,10 @@ class FusionTrainer:
         self.device = torch.device(device)
         self.accumulation_steps = accumulation_steps
         sd = {k: v for k, v in state_dict.items() if v.is_floating_point() and v.numel() > 0}
+        # BatchNorm's int64 update counters (six ``*.num_batches_tracked`` buffers): kept on the host, advanced by the
+        # number of train-mode applications of their layer (BnP.calls) and written back by state_dict(), so that the key
+        # set equals CompleteEnhancedFusionSR.state_dict()'s and a resumed run continues the count
+        self._nbt0 = {k: int(v) for k, v in state_dict.items() if k.endswith(".num_batches_tracked")}
         params = {k: v for k, v in sd.items() if fusion_train.is_parameter(k)}
         with torch.cuda.device(self.device):
             self.opt = FusionOptimizer(params, self.device, **opt_kwargs)
@@ -120,10 +124,14 @@ class FusionTrainer:
         """lr [B,h,w,3], hr [B,4h,4w,3], imgs / feats: dicts of channels-last maps on the device (cached expert outputs).
         Accumulates d loss / d parameters into the flat gradient buffer; returns (loss [1] device tensor, sr map)."""
         with torch.cuda.device(self.device), torch.no_grad():
-            sr = self.net.forward(self.tape, lr, imgs, feats)
-            loss, g = l1_clamp_loss(sr.v, hr, self.accumulation_steps)
-            sr.g, sr.gown = g, True
-            self.tape.backward()
+            self.tape.clear()      # closures left behind by a forward / backward that raised must never be replayed
+            try:
+                sr = self.net.forward(self.tape, lr, imgs, feats)
+                loss, g = l1_clamp_loss(sr.v, hr, self.accumulation_steps)
+                sr.g, sr.gown = g, True
+                self.tape.backward()
+            finally:
+                self.tape.clear()
         return loss, sr.v
 
     def step(self, lr, hr, imgs, feats, lr_rate: float = None):
@@ -143,4 +151,7 @@ class FusionTrainer:
         """reference-keyed state (parameters from the live weights or the EMA shadow, buffers incl. running statistics)"""
         out = {k: v.clone() for k, v in self.opt.views(self.opt.ema if ema else None).items()}
         out.update({k: v.clone() for k, v in self.buffers.items()})
+        for q, bn in self.net.batchnorms.items():
+            k = q + ".num_batches_tracked"
+            out[k] = torch.tensor(self._nbt0.get(k, 0) + bn.calls, dtype=torch.long)
         return out

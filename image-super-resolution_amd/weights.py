@@ -362,11 +362,30 @@ def _strip(sd, prefixes):
     return out
 
 
+def _numpy_scalar_globals():
+    """Allow-list for the weights-only unpickler: the reconstruction of numpy SCALARS and dtypes, nothing else.
+    The reference's trainer stores its validation metrics next to the weights (checkpoint_manager.py:125-136:
+    ``metrics``; the values are numpy.float64 wherever they come out of np.mean, metrics.py:365-366) -- pure data whose
+    constructors (numpy's ``scalar(dtype, bytes)`` and ``dtype(...)``) execute nothing from the file.  Both module
+    spellings are listed: numpy >= 2 pickles ``numpy._core.multiarray.scalar``, numpy 1.x ``numpy.core.multiarray.scalar``."""
+    import numpy
+    mod = getattr(numpy, "_core", None) or numpy.core
+    scalar = mod.multiarray.scalar
+    out = [(scalar, "numpy._core.multiarray.scalar"), (scalar, "numpy.core.multiarray.scalar"), numpy.dtype]
+    for t in ("float64", "float32", "float16", "int64", "int32", "int16", "int8", "uint8", "uint16", "uint32", "uint64", "bool"):
+        out.append(type(numpy.dtype(t)))
+    return out
+
+
 def load_checkpoint(path: str, kind: str) -> SD:
     """Reads one of the five checkpoint files with the reference's wrapper/prefix conventions
     (expert_loader.py:83-95, :378; io.py:165-167, :197-205).  Unlike the reference this uses
-    ``weights_only=True`` (nothing from the file is executed)."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    ``weights_only=True`` (nothing from the file is executed); the only additions to torch's default allow-list are
+    numpy's scalar / dtype constructors, so that a ``fusion_best.pth`` written by the reference's own
+    CheckpointManager.save_checkpoint (model + optimizer + scheduler state, numpy-valued ``metrics``, ``timestamp``, EMA
+    ``extra_state``) loads."""
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
     if kind in ("drct", "grl"):
         sd = _strip(_unwrap(ckpt, ("params_ema", "params", "state_dict", "model")), ("module.",))
     elif kind == "nafnet":

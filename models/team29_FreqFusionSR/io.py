@@ -8,7 +8,9 @@ contract (io.py:100-120).  Underneath, every image goes through the MI355X HIP e
 
 Multi-GPU: when launched with WORLD_SIZE > 1 (torchrun, one process per GPU) rank 0 reads the checkpoints and
 broadcasts them over RCCL, every rank processes ``images[rank::world]`` and joins at a barrier before
-returning, so test.py's timing around ``main`` stays valid.
+returning, so test.py's timing around ``main`` stays valid.  Without a launcher, ``FFSR_GPUS=N`` (or ``all``) makes a
+plain ``main(...)`` call -- test.py unchanged -- start ranks 1..N-1 itself as child processes (one per GPU, the
+reference's scheme: scripts/kaggle_inference_fixed.py:385-397), act as rank 0, and join them before it returns.
 """
 import glob
 import importlib
@@ -95,7 +97,81 @@ def _load_engine(model_dir, device):
     return engine.Engine(w, device, scale), rank, world
 
 
+WORKER_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "worker.py")
+
+
+def _self_launch(model_dir, input_path, output_path):
+    """FFSR_GPUS=N|all and no launcher around us: start ranks 1..N-1 (fresh processes running worker.py -> main) and turn
+    this process into rank 0 of the job.  Returns (procs, threads, saved environment) or None."""
+    want = os.environ.get("FFSR_GPUS", "").strip().lower()
+    if not want or "WORLD_SIZE" in os.environ:
+        return None
+    world = torch.cuda.device_count() if want == "all" else int(want)
+    if world <= 1:
+        return None
+    shard = _pkg("shard")
+    port = shard.free_port()
+    argv = [sys.executable, os.environ.get("FFSR_WORKER", WORKER_PATH), model_dir, input_path, output_path]
+    procs, threads, _ = shard.launch_ranks(world, argv, first_rank=1, port=port,
+                                           relay=lambda r, line, err: (sys.stderr.write(f"[rank {r}] {line}"), sys.stderr.flush()))
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+    saved = {k: os.environ.get(k) for k in keys}
+    os.environ.update({k: v for k, v in shard.rank_env(0, world, port, base={}).items() if k in keys})
+    # a helper that dies leaves rank 0 blocked in the rendezvous / broadcast / final barrier with no way to interrupt the
+    # collective from Python: a watchdog thread ends the whole job loudly instead (what a launcher's agent does)
+    import threading
+    state = {"done": False}
+
+    def watchdog():
+        import time
+        while not state["done"]:
+            for r, p in procs:
+                code = p.poll()
+                if code not in (None, 0) and not state["done"]:
+                    sys.stderr.write(f"\n[main] helper rank {r} exited with code {code}: aborting the multi-GPU run\n")
+                    sys.stderr.flush()
+                    for _, q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+                    os._exit(70)
+            time.sleep(0.2)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    return procs, threads, saved, state
+
+
+def _self_join(launched, failed):
+    procs, threads, saved, state = launched
+    state["done"] = True
+    shard = _pkg("shard")
+    if failed:                        # rank 0 is going down with an exception: do not leave the helpers blocked in a collective
+        for _, p in procs:
+            p.terminate()
+    rc = shard.join_ranks(procs, threads)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    if rc != 0 and not failed:
+        raise RuntimeError(f"a helper rank of the self-launched multi-GPU run exited with code {rc}")
+
+
 def main(model_dir, input_path, output_path, device=None):
+    launched = _self_launch(model_dir, input_path, output_path)
+    if launched is None:
+        return _main(model_dir, input_path, output_path, device)
+    ok = False
+    try:
+        _main(model_dir, input_path, output_path, device)
+        ok = True
+    finally:
+        _self_join(launched, failed=not ok)
+
+
+def _main(model_dir, input_path, output_path, device=None):
     device = _rank_device(device)
     print(f"\n{'=' * 60}\n  FreqFusionSR (MI355X HIP engine)\n{'=' * 60}")
     print(f"  Weights : {model_dir}\n  Input   : {input_path}\n  Output  : {output_path}\n  Device  : {device}\n")

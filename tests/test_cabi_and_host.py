@@ -74,6 +74,42 @@ def test_checkpoint_conventions(tmp_path):
         W.load_model_dir(str(tmp_path), templ)
 
 
+def test_trainer_format_checkpoint_loads(tmp_path):
+    """fusion_best.pth as the reference's own trainer writes it: CheckpointManager.save_checkpoint
+    (src/utils/checkpoint_manager.py:125-136) stores model / optimizer / scheduler state, ``metrics`` (numpy scalars wherever
+    they come out of np.mean: src/utils/metrics.py:365-366), an ISO ``timestamp`` and train.py:1117-1121's extra state (stage,
+    EMA shadow, decay).  The weights-only loader must read it (numpy scalar reconstruction is allow-listed, nothing else)
+    and must still refuse a pickle that wants to run code."""
+    import datetime
+    import numpy as np
+    W = mod("weights")
+    small = W.random_weights(seed=3, small=True)
+    W.save_model_dir(str(tmp_path), small)
+    fus = {k: v.clone() for k, v in small["fusion"].items()}
+    prm = [torch.nn.Parameter(v.clone()) for v in list(fus.values())[:4] if v.is_floating_point() and v.dim() > 0]
+    opt = torch.optim.AdamW(prm, lr=2e-4, weight_decay=1e-4)
+    sum((p * p).sum() for p in prm).backward()
+    opt.step()
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+    ckpt = {"epoch": 17, "model_state_dict": {"module." + k: v for k, v in fus.items()},
+            "optimizer_state_dict": opt.state_dict(),
+            "metrics": {"psnr": np.float64(31.4159), "ssim": np.float32(0.91), "count": np.int64(100), "loss": 0.0123},
+            "timestamp": datetime.datetime.now().isoformat(), "scheduler_state_dict": sched.state_dict(),
+            "stage": 2, "ema_shadow": {k: v.clone() for k, v in fus.items() if v.is_floating_point()}, "ema_decay": 0.999}
+    torch.save(ckpt, tmp_path / "fusion_best.pth")
+    got = W.load_model_dir(str(tmp_path), W.random_weights(seed=4, small=True, shapes_only=True))
+    for k, v in fus.items():
+        assert torch.equal(got["fusion"][k], v.float()), k
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    torch.save({"model_state_dict": fus, "metrics": Evil()}, tmp_path / "fusion_best.pth")
+    with pytest.raises(Exception):
+        W.load_checkpoint(str(tmp_path / "fusion_best.pth"), "fusion")
+
+
 def test_shapes_only_template_and_lazy_defaults(tmp_path):
     """io.main's loader path: the template carries keys + shapes only (meta tensors); values come from the files and the
     default initialisation is evaluated only for keys the files do not supply (expert_loader.py:97-111 keeps the

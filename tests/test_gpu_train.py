@@ -1,12 +1,14 @@
 """SURVEY 8 f2, optimiser side: the HIP loss / clip / AdamW / EMA kernels against torch's own autograd, AdamW and
 clip_grad_norm_ on the CPU (oracle/ffsr_oracle/train.py); cache formats.  The backward pass itself: tests/test_gpu_backward.py."""
 import importlib
+import os
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def mod(name):
@@ -162,3 +164,13 @@ def test_cached_dataset_entries_drive_the_training_step(tmp_path):
     assert all(0.0 < v < 1.0 for v in losses) and not torch.equal(tr.opt.param, p0)
     sd = tr.state_dict(ema=True)
     assert set(sd) >= {"refine.0.weight", "cross_band.lka_block.norm1.running_mean"}
+    # the key set is the reference's CompleteEnhancedFusionSR.state_dict() (manifest = its keys minus the six int64
+    # BatchNorm counters, oracle/make_manifest.py) so that load_state_dict(strict=True) accepts a checkpoint written from it;
+    # the counters advance once per train-mode application (9 bands share cross_band's block, 4 experts lka_global)
+    import json
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["fusion"]
+    bns = [q + n for q in ("cross_band.lka_block.", "collaborative.lka_global.") for n in ("norm1", "norm2", "lka.bn")]
+    assert set(sd) == set(man) | {b + ".num_batches_tracked" for b in bns}
+    assert all(sd[b + ".num_batches_tracked"].dtype == torch.long for b in bns)
+    assert int(sd["cross_band.lka_block.norm1.num_batches_tracked"]) == 9 * 2
+    assert int(sd["collaborative.lka_global.lka.bn.num_batches_tracked"]) == 4 * 2

@@ -51,7 +51,7 @@ WORKER = textwrap.dedent("""
     E.Engine = Engine
 
     from models.team29_FreqFusionSR import main
-    main(model_dir="unused", input_path=sys.argv[1], output_path=sys.argv[2], device=torch.device("cuda"))
+    main(model_dir="unused", input_path=sys.argv[-2], output_path=sys.argv[-1], device=torch.device("cuda"))
     print("LOG " + json.dumps(log))
 """)
 
@@ -101,3 +101,50 @@ def test_rank_device_single_process_keeps_the_callers_device(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "8"), monkeypatch.setenv("RANK", "5"), monkeypatch.setenv("LOCAL_RANK", "5")
     assert io._rank_device(torch.device("cuda")) == torch.device("cuda:5")
     assert io._rank_device(torch.device("cuda:2")) == torch.device("cuda:2")        # an explicit index wins
+
+
+def test_main_self_launches_its_helper_ranks(tmp_path):
+    """FFSR_GPUS=2 and NO launcher: one plain main(...) call (what test.py:67 does) starts rank 1 itself as a child
+    process, acts as rank 0 and joins the helper before it returns -- the reference's one-command multi-GPU start
+    (scripts/kaggle_inference_fixed.py:385-397).  gloo on CPU, engine stubbed (the stub script doubles as FFSR_WORKER)."""
+    from PIL import Image
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    names = [f"{i:04d}x4.png" for i in (3, 1, 7, 5, 2)]
+    rng = np.random.RandomState(1)
+    for n in names:
+        Image.fromarray(rng.randint(0, 256, (6, 8, 3)).astype(np.uint8)).save(inp / n)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FFSR_GPUS="2", FFSR_WORKER=str(script))
+    p = subprocess.run([sys.executable, str(script), str(inp), str(out)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout
+    assert "Processing 3 of 5 images on rank 0/2" in p.stdout and "Processing 2 of 5 images on rank 1/2" in p.stdout, p.stdout
+    assert sorted(os.listdir(out)) == sorted(names)
+    # a helper that dies must fail the call instead of leaving a partial result behind silently
+    bad = tmp_path / "bad_worker.py"
+    bad.write_text("import sys; sys.exit(7)\n")
+    env["FFSR_WORKER"] = str(bad)
+    p = subprocess.run([sys.executable, str(script), str(inp), str(tmp_path / "out2")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert p.returncode != 0
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the driver's command shape) starts the two rank processes itself,
+    relays exactly one JSON line on stdout and exits 0; a failing rank makes it exit non-zero.  --dry-run: the launch /
+    rendezvous / broadcast / MAX-over-ranks plumbing on gloo, no engine (there is no GPU here)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["ms_per_step"] >= 20.0      # the slower rank's time
+    p = subprocess.run(cmd + ["--backend", "no-such-backend"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=240)
+    assert p.returncode != 0
