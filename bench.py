@@ -316,7 +316,7 @@ def main():
             t = by_shape.setdefault(shape, [0, 0.0, 0.0, 0.0])
             t[0] += 1; t[1] += ms; t[2] += f; t[3] += nbytes
         for shape, (n, ms, f, nb) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('FFSR_BENCH_SHAPES', '14'))]:
-            log(f"  conv M={shape[0]:8d} N={shape[1]:4d} K={shape[2]:5d} k{shape[3]} {('f32in ', 'planes', 'strip ')[shape[4]]} x{n:4d}: "
+            log(f"  conv M={shape[0]:8d} N={shape[1]:4d} K={shape[2]:5d} k{shape[3]} {('f32in ', 'planes', 'strip ', 'tokmlp')[shape[4]]} x{n:4d}: "
                 f"{ms:7.1f} ms {1e3 * ms / n:7.1f} us {f / ms / 1e9:6.1f} TFLOP/s {nb / ms / 1e9:5.2f} TB/s (algorithmic bytes)")
         lp = ops.pad_reflect(lrs[0], (h + 15) // 16 * 16, (w + 15) // 16 * 16)
         for name, fn in (("drct", eng.drct), ("grl", eng.grl), ("nafnet", eng.nafnet), ("mamba", eng.mamba)):
@@ -328,7 +328,7 @@ def main():
         log(f"  conv/GEMM kernel: {len(prof)} launches, {flops / 1e12:.2f} TFLOP, {conv_s * 1e3:.1f} ms -> {achieved:.1f} TFLOP/s; "
             f"whole step {step_s * 1e3:.1f} ms")
     # ---- the dominant kernel FAMILY: conv / GEMM launches are grouped by the kernel that served them
-    # (prof entry: shape[4] = 1 for the pre-split-input planes GEMM, 2 for its 3x3 tap-strip variant, 0 for the fp32-input kernel)
+    # (prof entry: shape[4] = 1 for the pre-split-input planes GEMM, 2 for its 3x3 tap-strip variant, 3 for the fused token chain, 0 for the fp32-input kernel)
     fams = {}
     for (e0, e1, f, shape, nbytes), ms in zip(prof, dur_ms):
         t = fams.setdefault(int(shape[4]), [0, 0.0, 0.0, 0.0])
@@ -339,7 +339,10 @@ def main():
                  2: ("conv3_strip_planes_kernel", "conv3_strip_planes_kernel (3x3 implicit GEMM on pre-split planes; the three "
                      "horizontal taps share one LDS-DMA-staged strip of A rows; 3-term split-bf16 MFMA, fp32 accumulate)"),
                  0: ("conv_gemm_bf16x3_v3_kernel", "conv_gemm_bf16x3_v3_kernel (implicit GEMM; fp32 operands split on the fly, "
-                     "3-term split-bf16 MFMA, fp32 accumulate)")}
+                     "3-term split-bf16 MFMA, fp32 accumulate)"),
+                 3: ("tok_chain_kernel", "tok_chain_kernel (token-stationary fused LayerNorm + fc1 + GELU + fc2 + residual: rows "
+                     "in registers, hidden layer never leaves them, weights streamed fragment-major through LDS; 3-term "
+                     "split-bf16 MFMA 16x16x32, fp32 accumulate)")}
         mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
     else:
         names = {0: ("conv_gemm_kernel", "conv_gemm_kernel (f32-input MFMA implicit GEMM)")}

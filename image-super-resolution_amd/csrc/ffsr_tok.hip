@@ -1,0 +1,576 @@
+// Token-stationary fused chains:  out = epilogue( W2 . act( W1 . prologue(x) + b1 ) + b2 )  per token, one kernel.
+//
+// Why: the K <= 320 token GEMMs of the Swin / GRL blocks and NAFNet's pointwise halves are latency- and byte-bound as
+// separate launches (LayerNorm -> fc1 -> GELU -> fc2 -> +res = 3 launches, ~950 MB of HBM traffic per block at 340x510,
+// of which 2 x 277 MB is the hidden layer's round trip).  Here a wave owns 16 tokens for the whole chain:
+//   * its input row block lives in REGISTERS as the B operand of v_mfma_f32_16x16x32_bf16 (bf16 hi / lo planes, split
+//     on the fly from the fp32 row; optional LayerNorm of the row first -- the affine part is folded into W1 / b1 at
+//     pack time), lane = (token l & 15, k-quarter q = l >> 4);
+//   * both GEMMs are computed TRANSPOSED, D = W_tile (A operand: 16 output features x 32 k) x X^T (B operand: 32 k x
+//     16 tokens), so every result tile has its token on the LANE and 4 features in its 4 registers.  The activated
+//     hidden tile is therefore, after bf16 conversion, directly the B operand of the second GEMM (its k order is a
+//     fixed permutation that the packed W2 absorbs): the hidden layer never leaves the registers -- no LDS, no HBM;
+//   * the rows of W2 are packed in the order that makes lane q's output columns {32 s + 8 q + 0..7} -- the columns of
+//     the input row the same lane loaded.  When the residual IS the input row (x + mlp(norm(x))), the accumulators are
+//     simply initialised with the fp32 row: the residual costs no second read;
+//   * the weights stream through an LDS ring by LDS-DMA in FRAGMENT-MAJOR order (packed once at load time: each 1 KB
+//     piece is exactly one wave's A fragment, lane-linear), so staging needs no swizzle and every ds_read_b128 is a
+//     contiguous, conflict-free 1 KB read; all waves of the workgroup share the stream (one raw s_barrier per slot,
+//     counted vmcnt keeps D-2 slots in flight);
+//   * workgroups are PERSISTENT (one per CU) and walk a list of 16 x WAVES-token tiles; the ring of weight fills runs
+//     on across tile boundaries and the rows of the NEXT tile are loaded into registers while the current tile computes.
+//     (First version, one tile per workgroup: rocprof + ablation builds showed ~100 us of a 227 us launch was the
+//     exposed load / store phase -- at one workgroup per CU nothing overlapped it.)
+//   * products are 3-term split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate) like the other GEMM kernels;
+//   * the epilogue (bias, column scale, residual, optional LayerNorm of the output row + second residual, fp32 and / or
+//     bf16-plane stores) works per lane on 4 consecutive columns: 16-byte fp32 stores, 8-byte plane stores.
+// HBM traffic of a Swin MLP block: read x once, write out once.
+#include "ffsr_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct TokArgs {
+  const float* x;            // [M, ldx] fp32 rows, K channels used
+  const unsigned char* w1;   // fragment-major bf16 hi / lo of W1': [steps][G tiles][KS1][2][64 lanes][8]
+  const float* b1;           // [steps * G * 16] hidden bias in packed tile order (zero padded)
+  const unsigned char* w2;   // [steps][NT2][2][64][8], k slots in accumulator order, rows in the lane-column order
+  const float* b2;           // [N] or null
+  const float* cvec;         // [N] or null: column scale of (y + b2)
+  const float* res;          // [M, ldr] or null: added after the column scale (scaled by rscale * rvec[n])
+  const float* rvec;         // [N] or null
+  const float* g2;           // [N] post-LayerNorm weight or null (no post-LN)
+  const float* be2;          // [N] post-LayerNorm bias
+  const float* res2;         // [M, ldr2] or null: added after the post-LN
+  float* out;                // [M, ldo] or null
+  unsigned short* o_hi;      // planes [M, ldp] or null
+  unsigned short* o_lo;
+  int ldx, ldr, ldr2, ldo, ldp;
+  int M, K, N, steps;
+  int pre_ln;
+  int res_is_x;              // res == x (same rows, same stride), no column scale: the accumulators start from the input row
+  float eps1, eps2, cscale, rscale;
+  int act;                   // MODE 2: epilogue activation (FfsrAct)
+  float slope;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// tools/tok_ablate.sh builds this file with -DFFSR_TOK_ABL=<bits> (timing-only diagnostics, results are wrong):
+// 1 no activation math, 2 no fragment reads from LDS, 4 no barriers / waits, 8 no LDS-DMA fills, 16 no MFMAs
+#ifndef FFSR_TOK_ABL
+#define FFSR_TOK_ABL 0
+#endif
+__device__ __forceinline__ floatx4 mfma16(bf16x8 a, bf16x8 b, floatx4 c) {
+#if FFSR_TOK_ABL & 16
+  c[0] += __builtin_bit_cast(floatx4, a)[0] * __builtin_bit_cast(floatx4, b)[0];
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// erfc(|x|) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of an fp32 rounding of erf itself) -- one rcp,
+// one exp2, seven FMAs: the activation runs between the two GEMMs of a wave, where ocml's erff (~40 instructions with
+// branches) would cost as much issue time as the MFMAs it sits between.
+//   gelu(v) = 0.5 v (1 + erf(v / sqrt 2)) = v >= 0 ? v - 0.5 v E : 0.5 v E,   E = erfc(|v| / sqrt 2)   (no cancellation)
+__device__ __forceinline__ float gelu_fast(float v) {
+#if FFSR_TOK_ABL & 1
+  return v;
+#endif
+  const float ax = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+  const float hE = 0.5f * v * (pl * t * e);     // 0.5 v erfc(|x|)
+  return v >= 0.f ? v - hE : hE;
+}
+
+// 4 floats -> 4 bf16 hi (2 registers) + 4 bf16 lo
+__device__ __forceinline__ void split4(const floatx4 v, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+  ffsr_split2(v[0], v[1], h0, l0);
+  ffsr_split2(v[2], v[3], h1, l1);
+}
+
+// The wave's 16 rows, fp32, in operand order: lane (token l & 15, q = l >> 4) holds columns 32 s + 8 q + 4 h + 0..3.
+template <int KS1>
+__device__ __forceinline__ void tok_load_rows(const TokArgs& p, const float* xr, int q, floatx4 (&xv)[KS1][2]) {
+#pragma unroll
+  for (int s = 0; s < KS1; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 32 * s + 8 * q + 4 * h;
+      xv[s][h] = (k < p.K) ? *reinterpret_cast<const floatx4*>(xr + k) : floatx4{0.f, 0.f, 0.f, 0.f};   // K % 4 == 0
+    }
+}
+
+// rows -> (optionally normalised: two-pass LayerNorm statistics over the row, which is spread over the lanes l, l^16, l^32,
+// l^48) bf16 hi / lo B operands of the first GEMM.  xv is left untouched (it may serve as the residual).
+template <int KS1>
+__device__ __forceinline__ void tok_prepare(const TokArgs& p, int q, const floatx4 (&xv)[KS1][2], bf16x8 (&a_hi)[KS1],
+                                            bf16x8 (&a_lo)[KS1]) {
+  float mean = 0.f, rstd = 1.f;
+  if (p.pre_ln) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) s1 += (xv[s][h][0] + xv[s][h][1]) + (xv[s][h][2] + xv[s][h][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    mean = s1 / (float)p.K;
+    float s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool in = 32 * s + 8 * q + 4 * h < p.K;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = in ? xv[s][h][c] - mean : 0.f;
+          s2 = fmaf(d, d, s2);
+        }
+      }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    rstd = rsqrtf(s2 / (float)p.K + p.eps1);
+  }
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) {
+    floatx4 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool in = 32 * s + 8 * q + 4 * h < p.K;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[h][c] = in ? (xv[s][h][c] - mean) * rstd : 0.f;
+    }
+    unsigned hh[4], ll[4];
+    split4(v[0], hh[0], hh[1], ll[0], ll[1]);
+    split4(v[1], hh[2], hh[3], ll[2], ll[3]);
+    a_hi[s] = __builtin_bit_cast(bf16x8, uintx4{hh[0], hh[1], hh[2], hh[3]});
+    a_lo[s] = __builtin_bit_cast(bf16x8, uintx4{ll[0], ll[1], ll[2], ll[3]});
+  }
+}
+
+// Epilogue of a wave's 16 tokens: accumulator tile n of lane (token, q) holds columns 32 (n >> 1) + 8 q + 4 (n & 1) + 0..3
+// (the packed W2 row order), i.e. the same column groups the lane loaded of its input row.
+template <int NT2>
+__device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT2], long long tok, bool tok_ok, size_t row, int q) {
+  const int N = p.N;
+#pragma unroll
+  for (int n = 0; n < NT2; ++n) {
+    const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
+    floatx4 v = acc[n];
+    if (col < N) {            // N % 4 == 0: the four columns are valid together
+      if (p.b2) v += *reinterpret_cast<const floatx4*>(p.b2 + col);
+      if (!p.res_is_x) {
+        floatx4 cs = {p.cscale, p.cscale, p.cscale, p.cscale};
+        if (p.cvec) cs *= *reinterpret_cast<const floatx4*>(p.cvec + col);
+        v *= cs;
+        if (p.res) {
+          floatx4 rs = {p.rscale, p.rscale, p.rscale, p.rscale};
+          if (p.rvec) rs *= *reinterpret_cast<const floatx4*>(p.rvec + col);
+          v += *reinterpret_cast<const floatx4*>(p.res + row * p.ldr + col) * rs;
+        }
+      }
+    } else {
+      v = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    acc[n] = v;
+  }
+  if (p.g2) {       // LayerNorm over the N output columns of the token (two-pass), affine, second residual
+    float s1 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) s1 += (acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 / (float)N;
+    float s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      const bool in = 32 * (n >> 1) + 8 * q + 4 * (n & 1) < N;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = in ? acc[n][c] - mean : 0.f;
+        acc[n][c] = d;
+        s2 = fmaf(d, d, s2);
+      }
+    }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 / (float)N + p.eps2);
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
+      if (col < N) {
+        floatx4 v = acc[n] * rstd * *reinterpret_cast<const floatx4*>(p.g2 + col) + *reinterpret_cast<const floatx4*>(p.be2 + col);
+        if (p.res2) v += *reinterpret_cast<const floatx4*>(p.res2 + row * p.ldr2 + col);
+        acc[n] = v;
+      }
+    }
+  }
+  if (!tok_ok) return;
+#pragma unroll
+  for (int n = 0; n < NT2; ++n) {
+    const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
+    if (p.out && col < N) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + col) = acc[n];
+    if (p.o_hi && col < p.ldp) {      // columns N .. ldp-1 of the planes are written as zeros (acc is zero there)
+      unsigned h0, h1, l0, l1;
+      split4(acc[n], h0, h1, l0, l1);
+      *reinterpret_cast<uintx2*>(p.o_hi + (size_t)tok * p.ldp + col) = uintx2{h0, h1};
+      *reinterpret_cast<uintx2*>(p.o_lo + (size_t)tok * p.ldp + col) = uintx2{l0, l1};
+    }
+  }
+}
+
+// MODE 0: hidden = GELU(W1 x + b1)            (G = 2 tiles of 16 hidden features per 32-deep step of the second GEMM)
+// MODE 1: hidden = (W1a x + b1a) * (W1b x + b1b)   (SimpleGate; G = 4: tiles 0,1 = first halves, 2,3 = second halves)
+// MODE 2: no second GEMM: out = act(W1 pre(x) + b1) * cvec * cscale, 32 output features per step, stored per step (the rows of
+//         W1 are packed in the lane-column order, so a lane stores 8 consecutive columns per step); NT2 is unused (2)
+// RX: the residual is the input row itself (accumulators start from it; requires K == N, NT2 == 2 KS1)
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH>
+__global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
+  constexpr int G = MODE == 1 ? 4 : 2;
+  constexpr int F1 = G * KS1 * 2;                  // 1 KB pieces of a W1 fill
+  constexpr int F2 = MODE == 2 ? 0 : NT2 * 2;      // ... of a W2 fill
+  constexpr int FMAX = F1 > F2 ? F1 : F2;
+  constexpr int SLOT = FMAX * 1024;
+  constexpr int PPW = (FMAX + WAVES - 1) / WAVES;  // LDS-DMA instructions per wave and fill (padded with dummy pieces)
+  static_assert(!RX || NT2 == 2 * KS1, "residual-from-input needs the same column groups on both sides");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // D slots | WAVES dummy KB | b1 [steps * G * 16] floats
+  unsigned char* const dummy = smem + D * SLOT;
+  float* const b1s = reinterpret_cast<float*>(dummy + WAVES * 1024);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4;
+  const int nfill = MODE == 2 ? p.steps : 2 * p.steps;
+  const int ntile = (p.M + 16 * WAVES - 1) / (16 * WAVES);
+  const int my_tiles = (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles blockIdx.x, + gridDim.x, ...
+  const int total_fills = my_tiles * nfill;
+
+  // fill fg (counted over all tiles of this workgroup): f = fg % nfill; even f = W1 of step f/2, odd = W2 of step f/2 -> slot
+  // fg % D.  Every wave issues PPW pieces per fill (pieces past the fill's size and fills past the end go to the wave's dummy
+  // KB: the vmcnt bookkeeping stays uniform).
+  auto issue_fill = [&](int fg) {
+#if !(FFSR_TOK_ABL & 8)
+    const bool live = fg < total_fills;
+    const int f = fg % nfill;
+    const bool second = MODE != 2 && (f & 1);
+    const int npiece = second ? F2 : F1;
+    const unsigned char* src0 = MODE == 2 ? p.w1 + (size_t)f * (F1 * 1024)
+                              : (second ? p.w2 + (size_t)(f >> 1) * (F2 * 1024) : p.w1 + (size_t)(f >> 1) * (F1 * 1024));
+    unsigned char* slot = smem + (fg % D) * SLOT;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int i = wave + WAVES * j;
+      const bool ok = live && i < npiece;
+      const unsigned char* src = (ok ? src0 + (size_t)i * 1024 : p.w1) + lane * 16;
+      unsigned char* dst = ok ? slot + i * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+    }
+#endif
+  };
+
+#pragma unroll
+  for (int f = 0; f < D - 1; ++f) issue_fill(f);
+
+  // hidden bias -> LDS (read per step with one ds_read_b128 per tile; a global load inside the loop would make the compiler
+  // drain the LDS-DMA ring with vmcnt(0))
+  for (int i = threadIdx.x; i < p.steps * G * 16; i += WAVES * 64) b1s[i] = p.b1[i];
+
+  auto tile_row = [&](int tile, long long& tok, bool& ok) -> size_t {
+    tok = ((long long)tile * WAVES + wave) * 16 + (lane & 15);
+    ok = tok < p.M;
+    return (size_t)(ok ? tok : p.M - 1);
+  };
+
+  floatx4 xv[KS1][2];      // the rows of the tile about to be computed (fp32)
+  {
+    long long t_;
+    bool o_;
+    tok_load_rows<KS1>(p, p.x + tile_row(blockIdx.x, t_, o_) * p.ldx, q, xv);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bias stores (before the first barrier)
+
+  int fbase = 0;           // global fill index of this tile's fill 0
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x, fbase += nfill) {
+    long long tok;
+    bool tok_ok;
+    const size_t row = tile_row(tile, tok, tok_ok);
+    bf16x8 a_hi[KS1], a_lo[KS1];
+    tok_prepare<KS1>(p, q, xv, a_hi, a_lo);
+    floatx4 acc[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      if constexpr (RX) acc[n] = xv[n >> 1][n & 1];       // x + ...: the residual is the row we already hold
+      else acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    // PFETCH: the next tile's rows start their way from HBM now and are first touched after this tile's epilogue (48 .. 80
+    // registers in flight; the wide shapes, which would spill, fetch them after the epilogue instead)
+    auto fetch_next = [&]() {
+      // (unconditional: past the last tile it re-reads a valid row nobody uses -- a conditional load would keep the OLD rows
+      //  alive through the whole tile as the other arm of the merge, 48 .. 80 registers)
+      const int nt = min(tile + (int)gridDim.x, ntile - 1);
+      long long t_;
+      bool o_;
+      tok_load_rows<KS1>(p, p.x + tile_row(nt, t_, o_) * p.ldx, q, xv);
+    };
+    if constexpr (PFETCH) fetch_next();
+
+    if constexpr (MODE == 2) {
+      for (int st = 0; st < p.steps; ++st) {
+#if !(FFSR_TOK_ABL & 4)
+        wait_vm<(D - 2) * PPW>();      // (the stores of the last steps are younger than the fill waited for: conservative)
+        __builtin_amdgcn_s_barrier();
+#endif
+        issue_fill(fbase + st + D - 1);
+        const unsigned char* S1 = smem + ((fbase + st) % D) * SLOT + lane * 16;
+        floatx4 hx[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 0) * 1024);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 1) * 1024);
+            hx[g] = mfma16(wh, a_lo[s], hx[g]);
+            hx[g] = mfma16(wl, a_hi[s], hx[g]);
+            hx[g] = mfma16(wh, a_hi[s], hx[g]);
+          }
+        }
+        // lane (token, q): tile g holds the output columns 32 st + 8 q + 4 g + 0..3
+        const float* bs = b1s + st * 32 + 4 * q;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int col = 32 * st + 8 * q + 4 * g;
+          floatx4 v = hx[g] + *reinterpret_cast<const floatx4*>(bs + 16 * g);
+          if (p.act == FFSR_ACT_GELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = gelu_fast(v[c]);
+          } else if (p.act != FFSR_ACT_NONE) {      // ReLU / LeakyReLU (slope 0 / given)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * p.slope;
+          }
+          if (col < p.N) {
+            floatx4 cs = {p.cscale, p.cscale, p.cscale, p.cscale};
+            if (p.cvec) cs *= *reinterpret_cast<const floatx4*>(p.cvec + col);
+            v *= cs;
+          } else {
+            v = floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+          if (tok_ok) {
+            if (p.out && col < p.N) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + col) = v;
+            if (p.o_hi && col < p.ldp) {
+              unsigned h0, h1, l0, l1;
+              split4(v, h0, h1, l0, l1);
+              *reinterpret_cast<uintx2*>(p.o_hi + (size_t)tok * p.ldp + col) = uintx2{h0, h1};
+              *reinterpret_cast<uintx2*>(p.o_lo + (size_t)tok * p.ldp + col) = uintx2{l0, l1};
+            }
+          }
+        }
+      }
+      if constexpr (!PFETCH) fetch_next();
+      continue;
+    }
+    for (int st = 0; st < p.steps; ++st) {
+      // ---- first GEMM of the step: G hidden tiles from slot (fbase + 2 st) % D
+#if !(FFSR_TOK_ABL & 4)
+      wait_vm<(D - 2) * PPW>();
+      __builtin_amdgcn_s_barrier();
+#endif
+      issue_fill(fbase + 2 * st + D - 1);
+      const unsigned char* S1 = smem + ((fbase + 2 * st) % D) * SLOT + lane * 16;
+      floatx4 hx[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) hx[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#if FFSR_TOK_ABL & 2
+          const bf16x8 wh = a_hi[(s + 1) % KS1], wl = a_lo[(s + 1) % KS1];
+          asm volatile("" ::"v"(S1));
+#else
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 0) * 1024);
+          const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 1) * 1024);
+#endif
+          hx[g] = mfma16(wh, a_lo[s], hx[g]);
+          hx[g] = mfma16(wl, a_hi[s], hx[g]);
+          hx[g] = mfma16(wh, a_hi[s], hx[g]);
+        }
+      }
+      // ---- bias, activation, conversion: the two 16-feature tiles become the B operand of the second GEMM's k step
+      const float* bs = b1s + st * (G * 16) + 4 * q;
+      floatx4 ha, hb;
+      if constexpr (MODE == 1) {
+        ha = (hx[0] + *reinterpret_cast<const floatx4*>(bs)) * (hx[2] + *reinterpret_cast<const floatx4*>(bs + 32));
+        hb = (hx[1] + *reinterpret_cast<const floatx4*>(bs + 16)) * (hx[3] + *reinterpret_cast<const floatx4*>(bs + 48));
+      } else {
+        ha = hx[0] + *reinterpret_cast<const floatx4*>(bs);
+        hb = hx[1] + *reinterpret_cast<const floatx4*>(bs + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ha[c] = gelu_fast(ha[c]);
+          hb[c] = gelu_fast(hb[c]);
+        }
+      }
+      unsigned hh[4], ll[4];
+      split4(ha, hh[0], hh[1], ll[0], ll[1]);
+      split4(hb, hh[2], hh[3], ll[2], ll[3]);
+      const bf16x8 h_hi = __builtin_bit_cast(bf16x8, uintx4{hh[0], hh[1], hh[2], hh[3]});
+      const bf16x8 h_lo = __builtin_bit_cast(bf16x8, uintx4{ll[0], ll[1], ll[2], ll[3]});
+
+      // ---- second GEMM: one 32-deep k step of every output tile from slot (fbase + 2 st + 1) % D
+#if !(FFSR_TOK_ABL & 4)
+      wait_vm<(D - 2) * PPW>();
+      __builtin_amdgcn_s_barrier();
+#endif
+      issue_fill(fbase + 2 * st + D);
+      const unsigned char* S2 = smem + ((fbase + 2 * st + 1) % D) * SLOT + lane * 16;
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) {
+#if FFSR_TOK_ABL & 2
+        const bf16x8 wh = a_hi[n % KS1], wl = a_lo[n % KS1];
+        asm volatile("" ::"v"(S2));
+#else
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S2 + (n * 2 + 0) * 1024);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S2 + (n * 2 + 1) * 1024);
+#endif
+        acc[n] = mfma16(wh, h_lo, acc[n]);
+        acc[n] = mfma16(wl, h_hi, acc[n]);
+        acc[n] = mfma16(wh, h_hi, acc[n]);
+      }
+    }
+    tok_epilogue<NT2>(p, acc, tok, tok_ok, row, q);
+    if constexpr (!PFETCH) fetch_next();
+  }
+  wait_vm<0>();     // the dummy pieces of the last fills
+}
+
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH>
+int launch_tok(const TokArgs& a, hipStream_t st) {
+  constexpr int G = MODE == 1 ? 4 : 2;
+  constexpr int F1 = G * KS1 * 2, F2 = MODE == 2 ? 0 : NT2 * 2, FMAX = F1 > F2 ? F1 : F2;
+  const int lds = D * FMAX * 1024 + WAVES * 1024 + a.steps * G * 16 * 4;
+  if (lds > 160 * 1024) return FFSR_EINVAL;
+  static unsigned long long attr_set = 0;
+  static int num_cu = 0;
+  const void* fn = reinterpret_cast<const void*>(&tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH>);
+  if (ffsr_allow_dynamic_lds(&fn, 1, 160 * 1024, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FFSR_ELAUNCH;
+    num_cu = prop.multiProcessorCount;
+  }
+  const int per = WAVES * 16;
+  const int ntile = (a.M + per - 1) / per;
+  const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;     // small rings (NAFNet widths): two workgroups share a CU
+  const int grid = ntile < num_cu * wg_per_cu ? ntile : num_cu * wg_per_cu;
+  FFSR_LAUNCH((tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+  return ffsr_launch_status();
+}
+
+template <int KS1, int NT2, int MODE, bool RX>
+int launch_tok_w(const TokArgs& a, int waves, hipStream_t st) {
+  constexpr int G = MODE == 1 ? 4 : 2;
+  constexpr int FMAX = (MODE == 2 || G * KS1 * 2 > NT2 * 2) ? G * KS1 * 2 : NT2 * 2;
+  // ring depth: 4 slots while they fit in ~128 KB; the single-GEMM mode (one fill per short step, stores in the loop) 5
+  constexpr int D = MODE == 2 ? (FMAX * 5 <= 140 ? 5 : (FMAX * 4 <= 148 ? 4 : 3)) : (FMAX * 4 <= 128 ? 4 : 3);
+  // the next tile's rows are prefetched into registers where that fits the 256 registers of two waves per SIMD
+  constexpr bool PF8 = MODE == 2 || KS1 <= 8;
+  switch (waves) {
+    case 4: return launch_tok<KS1, NT2, 4, D, MODE, RX, true>(a, st);
+    case 8: return launch_tok<KS1, NT2, 8, D, MODE, RX, PF8>(a, st);
+    default: return FFSR_EINVAL;
+  }
+}
+
+}  // namespace
+
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                                  const float* cvec, const float* res, int ldr, const float* rvec, const float* g2,
+                                  const float* be2, const float* res2, int ldr2, float* out, int ldo, void* out_hi,
+                                  void* out_lo, int ldp, long long M, int K, int N, int steps, int mode, int pre_ln,
+                                  float eps1, float eps2, float cscale, float rscale, int waves, void* stream) {
+  FFSR_CHECK(x && w1 && b1 && w2 && (out || (out_hi && out_lo)) && M > 0 && M < (1ll << 31));
+  FFSR_CHECK(K > 0 && N > 0 && steps > 0 && (K & 3) == 0 && (N & 3) == 0 && ldx >= K && (ldx & 3) == 0);
+  FFSR_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)b1 & 3) == 0);
+  FFSR_CHECK(!out || (ldo >= N && (ldo & 3) == 0 && ((uintptr_t)out & 15) == 0));
+  FFSR_CHECK(!res || (ldr >= N && (ldr & 3) == 0 && ((uintptr_t)res & 15) == 0));
+  FFSR_CHECK(!res2 || (g2 && ldr2 >= N && (ldr2 & 3) == 0 && ((uintptr_t)res2 & 15) == 0));
+  FFSR_CHECK(!g2 || be2);
+  FFSR_CHECK((!b2 || ((uintptr_t)b2 & 15) == 0) && (!cvec || ((uintptr_t)cvec & 15) == 0) && (!rvec || ((uintptr_t)rvec & 15) == 0) &&
+             (!g2 || (((uintptr_t)g2 & 15) == 0 && ((uintptr_t)be2 & 15) == 0)));
+  FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= N && ldp < N + 32 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0));
+  FFSR_CHECK(mode == 0 || mode == 1);
+  TokArgs a;
+  a.x = x; a.w1 = (const unsigned char*)w1; a.b1 = b1; a.w2 = (const unsigned char*)w2; a.b2 = b2; a.cvec = cvec; a.res = res;
+  a.rvec = rvec; a.g2 = g2; a.be2 = be2; a.res2 = res2; a.out = out; a.o_hi = (unsigned short*)out_hi; a.o_lo = (unsigned short*)out_lo;
+  a.ldx = ldx; a.ldr = ldr; a.ldr2 = ldr2; a.ldo = ldo; a.ldp = ldp; a.M = (int)M; a.K = K; a.N = N; a.steps = steps;
+  a.pre_ln = pre_ln; a.eps1 = eps1; a.eps2 = eps2; a.cscale = cscale; a.rscale = rscale; a.act = 0; a.slope = 0.f;
+  const int ks1 = (K + 31) / 32, nt2 = (N + 31) / 32 * 2;      // an even number of 16-column tiles
+  // x + f(x): the residual is the row the wave holds anyway (no second read), when nothing scales either side
+  a.res_is_x = (res == x && ldr == ldx && K == N && !cvec && !rvec && cscale == 1.0f && rscale == 1.0f && nt2 == 2 * ks1) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (waves == 0) waves = 8;
+#define FFSR_TOK_CASE(KS, NT, MD)                                                       \
+  if (ks1 == KS && nt2 == NT && mode == MD)                                             \
+    return a.res_is_x ? launch_tok_w<KS, NT, MD, true>(a, waves, st) : launch_tok_w<KS, NT, MD, false>(a, waves, st)
+  // Swin / GRL MLPs (K = N = 180 .. 308)
+  FFSR_TOK_CASE(6, 12, 0);
+  FFSR_TOK_CASE(7, 14, 0);
+  FFSR_TOK_CASE(8, 16, 0);
+  FFSR_TOK_CASE(9, 18, 0);
+  FFSR_TOK_CASE(10, 20, 0);
+  // NAFNet pointwise halves (c = 64, 128)
+  FFSR_TOK_CASE(2, 4, 1);
+  FFSR_TOK_CASE(4, 8, 1);
+#undef FFSR_TOK_CASE
+  return FFSR_EINVAL;
+}
+
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_tok_gemm_f32(const float* x, int ldx, const void* w1, const float* b1, const float* cvec, float* out,
+                                 int ldo, void* out_hi, void* out_lo, int ldp, long long M, int K, int N, int pre_ln,
+                                 float eps1, int act, float slope, float cscale, int waves, void* stream) {
+  FFSR_CHECK(x && w1 && b1 && (out || (out_hi && out_lo)) && M > 0 && M < (1ll << 31));
+  FFSR_CHECK(K > 0 && N > 0 && (K & 3) == 0 && (N & 3) == 0 && ldx >= K && (ldx & 3) == 0);
+  FFSR_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)b1 & 3) == 0);
+  FFSR_CHECK(!out || (ldo >= N && (ldo & 3) == 0 && ((uintptr_t)out & 15) == 0));
+  FFSR_CHECK(!cvec || ((uintptr_t)cvec & 15) == 0);
+  FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= N && ldp < N + 32 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0));
+  FFSR_CHECK(act == FFSR_ACT_NONE || act == FFSR_ACT_GELU || act == FFSR_ACT_RELU || act == FFSR_ACT_LRELU);
+  TokArgs a = {};
+  a.x = x; a.w1 = (const unsigned char*)w1; a.b1 = b1; a.cvec = cvec; a.out = out;
+  a.o_hi = (unsigned short*)out_hi; a.o_lo = (unsigned short*)out_lo;
+  a.ldx = ldx; a.ldo = ldo; a.ldp = ldp; a.M = (int)M; a.K = K; a.N = N; a.steps = (N + 31) / 32;
+  a.pre_ln = pre_ln; a.eps1 = eps1; a.cscale = cscale; a.rscale = 1.f; a.act = act;
+  a.slope = act == FFSR_ACT_RELU ? 0.f : slope;
+  const int ks1 = (K + 31) / 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (waves == 0) waves = 8;
+  switch (ks1) {
+    case 2: return launch_tok_w<2, 2, 2, false>(a, waves, st);
+    case 4: return launch_tok_w<4, 2, 2, false>(a, waves, st);
+    case 6: return launch_tok_w<6, 2, 2, false>(a, waves, st);
+    case 7: return launch_tok_w<7, 2, 2, false>(a, waves, st);
+    case 8: return launch_tok_w<8, 2, 2, false>(a, waves, st);
+    case 9: return launch_tok_w<9, 2, 2, false>(a, waves, st);
+    case 10: return launch_tok_w<10, 2, 2, false>(a, waves, st);
+    default: return FFSR_EINVAL;
+  }
+}

@@ -23,14 +23,27 @@ class _Swin:
         self.fc2 = ops.pack_conv(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], device)
         self.bias = dev(sd[p + "attn.relative_position_bias_table"], device)     # [(2ws-1)^2, heads], gathered in-kernel
         self.scale = (dim // heads) ** -0.5
+        # x + mlp(norm2(x)) as ONE kernel (ffsr_tok_chain_f32: LayerNorm, fc1, GELU, fc2 and the residual; the hidden layer
+        # stays in registers).  drct_arch.py:77-95, :405-407
+        # norm1 + qkv as one kernel (LayerNorm in the GEMM's prologue, drct_arch.py:385-388 + :166)
+        self.qkv_t = ops.pack_tok_gemm(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], device,
+                                       ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"])) if ops.tok_gemm_ok(dim, 3 * dim) else None
+        self.mlp = ops.pack_tok_chain(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "mlp.fc2.weight"],
+                                      sd[p + "mlp.fc2.bias"], device, mode=0, ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"])) \
+            if ops.tok_chain_ok(dim, dim, 0) else None
 
     def __call__(self, x, B, H, W):
         """x [P, dim] (row stride may be wider) -> [P, dim]"""
         pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"   # LN / fc1 results go to the GEMMs as bf16 hi/lo planes
-        n = ops.layernorm(x, *self.n1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.n1)
-        qkv = ops.linear(n, self.qkv)
+        if self.qkv_t is not None and ops.tok_enabled():
+            qkv = ops.tok_gemm(x, self.qkv_t)
+        else:
+            n = ops.layernorm(x, *self.n1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.n1)
+            qkv = ops.linear(n, self.qkv)
         a = ops.window_attn(qkv, self.bias, B, H, W, self.dim, self.heads, self.ws, self.shift, self.scale)
         y = ops.linear(a, self.proj, res=x)
+        if self.mlp is not None and ops.tok_enabled():
+            return ops.tok_chain(y, self.mlp, res=y)
         if not pl:
             h = ops.linear(ops.layernorm(y, *self.n2), self.fc1, act=ACT_GELU)
             return ops.linear(h, self.fc2, res=y)
@@ -55,7 +68,9 @@ class DRCT:
                 h = heads if j == 0 else heads - (dim % heads)
                 sw = _Swin(sd, f"layers.{i}.swin{j + 1}.", device, dim, h, ws, ws // 2 if j % 2 else 0)
                 adj = ops.pack_conv(sd[f"layers.{i}.adjust{j + 1}.weight"], sd[f"layers.{i}.adjust{j + 1}.bias"], device)
-                blocks.append((sw, adj))
+                adj_t = ops.pack_tok_gemm(sd[f"layers.{i}.adjust{j + 1}.weight"], sd[f"layers.{i}.adjust{j + 1}.bias"], device) \
+                    if (j < 4 and ops.tok_gemm_ok(dim, gc)) else None
+                blocks.append((sw, adj, adj_t))
             self.groups.append(blocks)
         self.tail = SRTail(sd, device)
 
@@ -72,10 +87,12 @@ class DRCT:
         cur = 0
         for blocks in self.groups:
             buf = cat[cur]
-            for j, (sw, adj) in enumerate(blocks):
+            for j, (sw, adj, adj_t) in enumerate(blocks):
                 dim = E + gc * j
                 y = sw(buf[:, :dim], B, H, W)
-                if j < 4:
+                if j < 4 and adj_t is not None and ops.tok_enabled():
+                    ops.tok_gemm(y, adj_t, act=ACT_LRELU, slope=0.2, out=buf[:, dim:dim + gc])
+                elif j < 4:
                     ops.linear(y, adj, act=ACT_LRELU, slope=0.2, out=buf[:, dim:dim + gc])
                 else:
                     ops.linear(y, adj, cscale=0.2, res=buf[:, :E], out=cat[1 - cur][:, :E])     # x5 * 0.2 + x

@@ -68,6 +68,9 @@ class _Block:
         self.cab = CAB(sd, p + "conv.", device)
         self.fc1 = ops.pack_conv(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], device)
         self.fc2 = ops.pack_conv(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], device)
+        # y + norm2(mlp(y)) as ONE kernel (fc1, GELU, fc2, LayerNorm of the output row, residual; fp32 + planes out)
+        self.mlp = ops.pack_tok_chain(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "mlp.fc2.weight"],
+                                      sd[p + "mlp.fc2.bias"], device, mode=0) if ops.tok_chain_ok(dim, dim, 0) else None
 
     def __call__(self, x, B, H, W, xp=None):
         """x [P, dim] contiguous tokens (xp: the same tensor as bf16 hi/lo planes, if the producer emitted them)
@@ -87,6 +90,9 @@ class _Block:
             y = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W)
             m = ops.linear(ops.linear(y, self.fc1, act=ACT_GELU), self.fc2)
             return ops.layernorm(m, *self.n2, res1=y), None
+        if self.mlp is not None and ops.tok_enabled():
+            y = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W)
+            return ops.tok_chain(y, self.mlp, post_ln=self.n2, res2=y, out_planes=True)
         y, yp = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W, out_planes=True)
         m = ops.linear(ops.linear(yp, self.fc1, act=ACT_GELU, out_planes=True, want_f32=False), self.fc2)
         return ops.layernorm(m, *self.n2, res1=y, out_planes=True)

@@ -24,6 +24,10 @@ class _VSS:
         self.skip2 = dev(sd[p + "skip_scale2"], device)
         self.in_proj = ops.pack_conv(sd[s + "in_proj.weight"], None, device)
         self.Dm = self.in_proj.N // 2
+        # ln_1 + in_proj as one kernel (mambair_arch.py:417 + :238)
+        C_ = sd[s + "in_proj.weight"].shape[1]
+        self.in_proj_t = ops.pack_tok_gemm(sd[s + "in_proj.weight"], None, device, ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])) \
+            if ops.tok_gemm_ok(C_, 2 * self.Dm) else None
         self.dw = ops.pack_dwconv(sd[s + "conv2d.weight"], sd[s + "conv2d.bias"], device)
         xw = sd[s + "x_proj_weight"].float()                                  # [4, R+2N, Dm]
         self.R = xw.shape[1] - 32
@@ -40,8 +44,11 @@ class _VSS:
         """x [P, C] tokens -> [P, C]"""
         Dm = self.Dm
         pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"
-        n1 = ops.layernorm(x, *self.ln1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.ln1)
-        xz = ops.linear(n1, self.in_proj)                                     # [P, 2*Dm] = x | z
+        if self.in_proj_t is not None and ops.tok_enabled():
+            xz = ops.tok_gemm(x, self.in_proj_t)                              # [P, 2*Dm] = x | z
+        else:
+            n1 = ops.layernorm(x, *self.ln1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.ln1)
+            xz = ops.linear(n1, self.in_proj)
         u = ops.dwconv2d(to_map(xz[:, :Dm], B, H, W), self.dw, act=ACT_SILU)  # [B,H,W,Dm]
         ut = tokens(u)
         xdbl = ops.linear(ut, self.x_proj)                                    # [P, 4*(R+32)]

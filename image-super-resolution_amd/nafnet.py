@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .common import dev
+from .common import dev, to_map, tokens
 
 
 class _Block:
@@ -29,19 +29,40 @@ class _Block:
         self.conv5 = ops.pack_conv(sd[p + "conv5.weight"], sd[p + "conv5.bias"], device)
         self.beta = dev(sd[p + "beta"].reshape(-1), device)
         self.gamma = dev(sd[p + "gamma"].reshape(-1), device)
+        # second half of the block, y + gamma * conv5(SimpleGate(conv4(norm2(y)))) (nafnet_arch.py:125-131), as ONE kernel at the
+        # shallow levels (c = 64, 128: ffsr_tok_chain_f32 mode 1).  gamma is folded into conv5 (diag(gamma) W5, gamma * b5), so the
+        # residual is the input row the kernel holds anyway: one read and one write of the map instead of seven passes.
+        # first half: norm1 + conv1 as one kernel (nafnet_arch.py:113-115)
+        self.conv1_t = ops.pack_tok_gemm(sd[p + "conv1.weight"], sd[p + "conv1.bias"], device,
+                                         ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"]), eps=1e-6) \
+            if (c <= 128 and ops.tok_gemm_ok(c, 2 * c)) else None
+        self.ffn = None
+        if ops.tok_chain_ok(c, c, 1):
+            gam = sd[p + "gamma"].detach().float().reshape(-1)
+            w5 = sd[p + "conv5.weight"].detach().float().reshape(c, c)
+            self.ffn = ops.pack_tok_chain(sd[p + "conv4.weight"], sd[p + "conv4.bias"], w5 * gam[:, None].to(w5.device),
+                                          sd[p + "conv5.bias"].detach().float() * gam.to(w5.device), device, mode=1,
+                                          ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]), eps=1e-6)
 
     def __call__(self, x):
         c = self.c
         # deep levels (c >= 256: long K, few pixels) are MFMA-heavy: their LayerNorm outputs go to the GEMM as bf16
         # hi/lo planes; the shallow levels are HBM-bound either way and keep the fp32 path
         pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3" and c >= 256
-        t = ops.layernorm(x, *self.n1, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
-        t = ops.conv2d(t, self.conv1)
+        if self.conv1_t is not None and ops.tok_enabled() and ops.rows(x) > 64 * 24:
+            Bx, Hx, Wx, _ = x.shape
+            t = to_map(ops.tok_gemm(tokens(x), self.conv1_t), Bx, Hx, Wx)
+        else:
+            t = ops.layernorm(x, *self.n1, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
+            t = ops.conv2d(t, self.conv1)
         g, pooled = ops.dw3x3_gate_pool(t, self.dw)              # SimpleGate + global average pool
         sca = ops.linear(pooled, self.sca)                       # [B, c] channel attention
         y = ops.conv2d(g, self.conv3, akscale=sca.contiguous(), res=x, cvec=self.beta)   # x + conv3(g*sca)*beta
-        t = ops.layernorm(y, *self.n2, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
         B, H, W, _ = y.shape
+        if self.ffn is not None and ops.tok_enabled() and B * H * W > 64 * 24:
+            yt = tokens(y)
+            return to_map(ops.tok_chain(yt, self.ffn, res=yt), B, H, W)
+        t = ops.layernorm(y, *self.n2, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
         if self.conv4g is not None and ops.GEMM_MODE == "bf16x3" and ops.GATE_FUSED and B * H * W > 64 * 24:
             g = ops.conv2d(t, self.conv4g, gate=True)            # conv4 + SimpleGate in one kernel
         else:

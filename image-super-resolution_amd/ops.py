@@ -401,6 +401,216 @@ def linear(x2d, cv: Conv, **kw):
     return y if isinstance(y, Planes) else mat(y)
 
 
+# ---------------------------------------------------------------------------------------------- token-stationary chains
+@dataclass
+class TokChain:
+    """Weights of a per-token chain  W2 . act(W1 . pre(x) + b1) + b2  packed for ffsr_tok_chain_f32 (fragment-major bf16
+    hi / lo: every 1 KB piece is one wave's MFMA A fragment, lane-linear)."""
+    w1: torch.Tensor          # bf16 [steps, G, KS1, 2, 64, 8]
+    b1: torch.Tensor          # fp32 [steps * G * 16]
+    w2: torch.Tensor          # bf16 [steps, NT2, 2, 64, 8]
+    b2: Optional[torch.Tensor]
+    K: int
+    N: int
+    H: int                    # true hidden width (algorithmic flops)
+    steps: int
+    mode: int                 # 0: GELU MLP, 1: SimpleGate
+    pre_ln: bool
+    eps1: float
+
+
+TOK_SHAPES = {0: ((6, 12), (7, 14), (8, 16), (9, 18), (10, 20)), 1: ((2, 4), (4, 8))}
+
+
+def tok_chain_ok(K: int, N: int, mode: int) -> bool:
+    return K % 4 == 0 and N % 4 == 0 and ((K + 31) // 32, (N + 31) // 32 * 2) in TOK_SHAPES[mode]
+
+
+def _split_bf16(w: torch.Tensor):
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16) if WEIGHT_LO else torch.zeros_like(hi)
+    return hi, lo
+
+
+def pack_tok_chain(w1, b1, w2, b2, device, *, mode=0, ln=None, eps=1e-5) -> TokChain:
+    """w1 [H, K] (+ b1 [H]), w2 [N, H'] (+ b2 [N]) as nn.Linear / 1x1 nn.Conv2d weights; H' = H (mode 0) or H / 2 (mode 1,
+    SimpleGate: hidden rows 0..H/2-1 times rows H/2..H-1).  ln = (gamma, beta): the chain starts with nn.LayerNorm(K); its
+    affine part is folded into the first layer (W1' = W1 diag(gamma), b1' = b1 + W1 beta), the kernel only normalises.
+    Load-time weight preparation with torch ops on `device`."""
+    w1 = w1.detach().float().to(device).reshape(w1.shape[0], -1)
+    w2 = w2.detach().float().to(device).reshape(w2.shape[0], -1)
+    H, K = w1.shape
+    N, H2 = w2.shape
+    b1 = torch.zeros(H, device=device) if b1 is None else b1.detach().float().to(device).reshape(-1)
+    if ln is not None:
+        gamma, beta = (t.detach().float().to(device).reshape(-1) for t in ln)
+        b1 = b1 + w1 @ beta
+        w1 = w1 * gamma[None, :]
+    assert tok_chain_ok(K, N, mode), (K, N, mode)
+    KS1, NT2 = (K + 31) // 32, (N + 31) // 32 * 2
+    Hg = H2                                      # width of the second GEMM's contraction
+    assert Hg == (H // 2 if mode == 1 else H)
+    steps = (Hg + 31) // 32
+    Hp = steps * 32
+
+    # ---- first layer: rows in tile order.  mode 0: natural; mode 1: per step [x1 a, x1 b, x2 a, x2 b]
+    def rows_padded(w, b, n):
+        wp = torch.zeros(Hp, KS1 * 32, device=device)
+        bp = torch.zeros(Hp, device=device)
+        wp[:n, :K] = w
+        bp[:n] = b
+        return wp, bp
+
+    if mode == 0:
+        wp, bp = rows_padded(w1, b1, H)
+        wt = wp.reshape(steps, 2, 16, KS1 * 32)
+        bt = bp.reshape(steps, 2, 16)
+    else:
+        wa, ba = rows_padded(w1[:Hg], b1[:Hg], Hg)
+        wb, bb = rows_padded(w1[Hg:], b1[Hg:], Hg)
+        wt = torch.cat([wa.reshape(steps, 2, 16, KS1 * 32), wb.reshape(steps, 2, 16, KS1 * 32)], 1)   # [steps, 4, 16, Kp]
+        bt = torch.cat([ba.reshape(steps, 2, 16), bb.reshape(steps, 2, 16)], 1)
+    G = wt.shape[1]
+    # A fragment of tile (st, g), k step s: lane (q = l >> 4, r = l & 15) holds W[16 tile + r][32 s + 8 q + j]
+    f1 = wt.reshape(steps, G, 16, KS1, 4, 8).permute(0, 1, 3, 4, 2, 5).reshape(steps, G, KS1, 64, 8)
+    h1, l1 = _split_bf16(f1)
+    w1p = torch.stack([h1, l1], 3).contiguous()                              # [steps, G, KS1, 2, 64, 8]
+    # ---- second layer: tile nt, step st: lane (q, r) element j holds W2[16 nt + r][32 st + 16 (j >> 2) + 4 q + (j & 3)]
+    # (the order in which the first GEMM's accumulators hold the hidden features of a token)
+    # rows in the LANE-COLUMN order: tile nt, row r holds output feature 32 (nt >> 1) + 8 (r >> 2) + 4 (nt & 1) + (r & 3), so
+    # that lane q of the kernel ends up with the output columns 32 s + 8 q + 0..7 -- the columns of the input row it loaded
+    w2n = torch.zeros(NT2 * 16, Hp, device=device)
+    w2n[:N, :Hg] = w2
+    nt_ = torch.arange(NT2, device=device)[:, None]
+    r_ = torch.arange(16, device=device)[None, :]
+    w2p_ = w2n[(32 * (nt_ // 2) + 8 * (r_ // 4) + 4 * (nt_ % 2) + (r_ % 4)).reshape(-1)]
+    f2 = w2p_.reshape(NT2, 16, steps, 2, 4, 4).permute(2, 0, 4, 1, 3, 5).reshape(steps, NT2, 64, 8)
+    h2, l2 = _split_bf16(f2)
+    w2p = torch.stack([h2, l2], 2).contiguous()                              # [steps, NT2, 2, 64, 8]
+    b2p = None
+    if b2 is not None:
+        b2p = torch.zeros(NT2 * 16, device=device)
+        b2p[:N] = b2.detach().float().to(device).reshape(-1)
+    return TokChain(w1p, bt.reshape(-1).contiguous(), w2p, b2p, K, N, H, steps, mode, ln is not None, float(eps))
+
+
+@dataclass
+class TokGemm:
+    """A linear layer (optionally preceded by a LayerNorm) packed for ffsr_tok_gemm_f32."""
+    w1: torch.Tensor          # bf16 [steps, 2, KS1, 2, 64, 8]
+    b1: torch.Tensor          # fp32 [steps * 32]
+    K: int
+    N: int
+    pre_ln: bool
+    eps1: float
+
+
+TOK_GEMM_KS = (2, 4, 6, 7, 8, 9, 10)
+
+
+def tok_gemm_ok(K: int, N: int) -> bool:
+    return K % 4 == 0 and N % 4 == 0 and (K + 31) // 32 in TOK_GEMM_KS
+
+
+def pack_tok_gemm(w, b, device, *, ln=None, eps=1e-5) -> TokGemm:
+    """w [N, K] (+ b [N]) as an nn.Linear / 1x1 nn.Conv2d weight; ln = (gamma, beta) of a LayerNorm(K) in front of it (folded:
+    W' = W diag(gamma), b' = b + W beta; the kernel only normalises)."""
+    w = w.detach().float().to(device).reshape(w.shape[0], -1)
+    N, K = w.shape
+    b = torch.zeros(N, device=device) if b is None else b.detach().float().to(device).reshape(-1)
+    if ln is not None:
+        gamma, beta = (t.detach().float().to(device).reshape(-1) for t in ln)
+        b = b + w @ beta
+        w = w * gamma[None, :]
+    assert tok_gemm_ok(K, N), (K, N)
+    KS1, steps = (K + 31) // 32, (N + 31) // 32
+    wn = torch.zeros(steps * 32, KS1 * 32, device=device)
+    bn = torch.zeros(steps * 32, device=device)
+    wn[:N, :K] = w
+    bn[:N] = b
+    # rows in the lane-column order: step st, tile g, row r holds output feature 32 st + 8 (r >> 2) + 4 g + (r & 3)
+    st_ = torch.arange(steps, device=device)[:, None, None]
+    g_ = torch.arange(2, device=device)[None, :, None]
+    r_ = torch.arange(16, device=device)[None, None, :]
+    perm = (32 * st_ + 8 * (r_ // 4) + 4 * g_ + (r_ % 4)).reshape(-1)
+    wt, bt = wn[perm].reshape(steps, 2, 16, KS1 * 32), bn[perm]
+    f1 = wt.reshape(steps, 2, 16, KS1, 4, 8).permute(0, 1, 3, 4, 2, 5).reshape(steps, 2, KS1, 64, 8)
+    h1, l1 = _split_bf16(f1)
+    return TokGemm(torch.stack([h1, l1], 3).contiguous(), bt.contiguous(), K, N, ln is not None, float(eps))
+
+
+def tok_gemm(x2d, tg: TokGemm, *, act=ACT_NONE, slope=0.0, cvec=None, cscale=1.0, out=None, out_planes=None, want_f32=True):
+    """x2d [M, >=K] fp32 rows -> act(W pre(x) + b) * cvec * cscale as [M, N] fp32 and / or planes (see tok_chain)."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.shape[1] >= tg.K
+    M = x2d.shape[0]
+    if out_planes is True:
+        out_planes = Planes(1, 1, M, tg.N, x2d.device)
+    if out is None and (want_f32 or out_planes is None):
+        out = torch.empty(M, tg.N, device=x2d.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    hip.call("ffsr_tok_gemm_f32", _ptr(x2d), x2d.stride(0), _ptr(tg.w1), _ptr(tg.b1), _ptr(cvec), _ptr(out),
+             0 if out is None else out.stride(0), None if out_planes is None else _ptr(out_planes.hi),
+             None if out_planes is None else _ptr(out_planes.lo), 0 if out_planes is None else out_planes.Cp, M, tg.K, tg.N,
+             int(tg.pre_ln), tg.eps1, act, float(slope), float(cscale), tok_waves(M, (tg.K + 31) // 32), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * tg.K * tg.N, (M, tg.N, tg.K, 1, 3), 4.0 * (M * tg.K + tg.N * tg.K + M * tg.N)))
+    if out_planes is not None:
+        return (out, out_planes) if out is not None else out_planes
+    return out
+
+
+TOK_WAVES = int(os.environ.get("FFSR_TOK_WAVES", "0"))
+TOK_FUSED = os.environ.get("FFSR_TOK", "1") != "0"   # FFSR_TOK=0: LayerNorm / fc1 / fc2 stay separate launches (A/B runs)
+
+
+def tok_enabled() -> bool:
+    """the fused token chains replace launches of the split-bf16 mode only (the exact f32 mode keeps the f32-MFMA GEMMs)"""
+    return TOK_FUSED and GEMM_MODE == "bf16x3"
+
+
+def tok_waves(M: int, KS1: int) -> int:
+    """waves (of 16 tokens) per persistent workgroup: 8 (two per SIMD); 4 when that leaves most of the chip's CUs without a tile"""
+    if TOK_WAVES:
+        return TOK_WAVES
+    return 8 if M >= 128 * 256 else 4
+
+
+def tok_chain(x2d, tc: TokChain, *, res=None, rscale=1.0, rvec=None, cvec=None, cscale=1.0, post_ln=None, eps2=1e-5,
+              res2=None, out=None, out_planes=None, want_f32=True):
+    """x2d [M, >=K] fp32 rows -> [M, N]:  y = (W2 act(W1 pre(x) + b1) + b2) * cvec * cscale + res * rvec * rscale;
+    post_ln = (gamma, beta): out = LayerNorm(y) * gamma + beta (+ res2).  out_planes: True / a Planes -> also emit bf16
+    hi / lo planes (returns (out, planes), or only the planes when want_f32 is False)."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.shape[1] >= tc.K
+    M = x2d.shape[0]
+    if out_planes is True:
+        out_planes = Planes(1, 1, M, tc.N, x2d.device)
+    if out is None and (want_f32 or out_planes is None):
+        out = torch.empty(M, tc.N, device=x2d.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    g2, be2 = post_ln if post_ln is not None else (None, None)
+    hip.call("ffsr_tok_chain_f32", _ptr(x2d), x2d.stride(0), _ptr(tc.w1), _ptr(tc.b1), _ptr(tc.w2), _ptr(tc.b2), _ptr(cvec),
+             _ptr(res), 0 if res is None else res.stride(0), _ptr(rvec), _ptr(g2), _ptr(be2), _ptr(res2),
+             0 if res2 is None else res2.stride(0), _ptr(out), 0 if out is None else out.stride(0),
+             None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
+             0 if out_planes is None else out_planes.Cp, M, tc.K, tc.N, tc.steps, tc.mode, int(tc.pre_ln), tc.eps1, float(eps2),
+             float(cscale), float(rscale), tok_waves(M, (tc.K + 31) // 32), _stream())
+    if prof is not None:
+        e1.record()
+        Hc = tc.H if tc.mode == 0 else tc.H // 2
+        prof.append((e0, e1, 2.0 * M * (tc.K * tc.H + Hc * tc.N), (M, tc.N, tc.K, 1, 3),
+                     4.0 * (M * tc.K + tc.H * tc.K + tc.N * Hc + M * tc.N * (1 + (res is not None) + (res2 is not None)))))
+    if out_planes is not None:
+        return (out, out_planes) if out is not None else out_planes
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- row kernels
 def _mat(t: torch.Tensor):
     """(tensor, M, C, ld) for a map or a 2-D matrix."""

@@ -73,6 +73,43 @@ int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, const void* w
                        int N, int ldo, int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
                        float cscale, float rscale, int bm, int bn, int stages, void* stream);
 
+/* Token-stationary fused chain: per token row x [K] (fp32, row stride ldx)
+ *     h   = act1( W1 . pre(x) + b1 )              pre = identity or the normalisation (x - mean) * rstd of nn.LayerNorm
+ *                                                 (its affine part is folded into W1 / b1 by the packer)
+ *     y   = (W2 . h + b2) * cvec * cscale + res * rvec * rscale
+ *     out = g2 ? LayerNorm_N(y) * g2 + be2 + res2 : y         -> fp32 `out` and / or bf16 hi / lo planes [M, ldp]
+ * in ONE kernel: a wave keeps its 16 tokens' rows in registers as MFMA operands, the hidden layer h never leaves the
+ * registers, W1 / W2 stream through LDS in fragment-major order (packed by image-super-resolution_amd/ops.py::pack_tok_chain:
+ * w1 = bf16 [steps][G][ceil(K/32)][2 planes][64 lanes][8], b1 = fp32 [steps * G * 16] in the same tile order,
+ * w2 = bf16 [steps][ceil(N/16)][2][64][8] with the k slots in accumulator order).  Products are 3-term split-bf16 MFMAs.
+ * mode 0 (G = 2): act1 = exact-erf GELU (erfc by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7), 32 hidden features per step:
+ *   the Swin / GRL Mlp with its LayerNorm and residual -- drct_arch.py:77-95 + :405-407 (x + mlp(norm2(x))), GRL's post-norm
+ *   form mixed_attn_block_efficient.py:543-554 (x + norm2(mlp(x))), swin_v1_block.py Mlp.
+ * mode 1 (G = 4): SimpleGate, h = (W1a x + b1a) * (W1b x + b1b), 32 gated features per step: NAFBlock's second half
+ *   y + gamma * conv5(SimpleGate(conv4(norm2(y)))), nafnet_arch.py:125-131.
+ * K, N % 4 == 0; supported (ceil(K/32), ceil(N/16)): (6,12) (7,14) (8,16) (9,18) (10,20) for mode 0, (2,4) (4,8) for mode 1.
+ * waves: 8, 11 or 12 waves of 16 tokens per workgroup (0 = 8). */
+int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                       const float* cvec, const float* res, int ldr, const float* rvec, const float* g2,
+                       const float* be2, const float* res2, int ldr2, float* out, int ldo, void* out_hi, void* out_lo,
+                       int ldp, long long M, int K, int N, int steps, int mode, int pre_ln, float eps1, float eps2,
+                       float cscale, float rscale, int waves, void* stream);
+
+/* Token-stationary single GEMM with the producer fused in front: per token row x [K] (fp32, row stride ldx)
+ *     out = act( W1 . pre(x) + b1 ) * cvec * cscale       -> fp32 `out` [M, ldo] and / or bf16 hi / lo planes [M, ldp]
+ * pre = identity or nn.LayerNorm's normalisation (affine part folded into W1 / b1 by the packer).  Same kernel family as
+ * ffsr_tok_chain_f32 (rows in registers as MFMA operands, W1 streamed fragment-major through LDS by LDS-DMA, persistent
+ * workgroups with the next tile's rows in flight, 3-term split-bf16 products), 32 output features per step, stored as they
+ * are produced.  w1 = bf16 [ceil(N/32)][2][ceil(K/32)][2 planes][64][8] with the rows in the lane-column order, b1 = fp32
+ * [ceil(N/32) * 32] in the same order (image-super-resolution_amd/ops.py::pack_tok_gemm).  act: none / GELU / ReLU / LeakyReLU.
+ * K, N % 4 == 0; ceil(K/32) in {2, 4, 6, 7, 8, 9, 10}.  Replaces LayerNorm + nn.Linear pairs whose LayerNorm output has no
+ * other consumer: norm1 + qkv of the Swin blocks (drct_arch.py:385-388 + :166), ln_1 + in_proj of the VSS blocks
+ * (mambair_arch.py:417 + :238), norm1 + conv1 of the NAFBlocks (nafnet_arch.py:113-115), and the dense-block 1x1 "adjust"
+ * convolutions + LeakyReLU (drct_arch.py:292-301). */
+int ffsr_tok_gemm_f32(const float* x, int ldx, const void* w1, const float* b1, const float* cvec, float* out, int ldo,
+                      void* out_hi, void* out_lo, int ldp, long long M, int K, int N, int pre_ln, float eps1, int act,
+                      float slope, float cscale, int waves, void* stream);
+
 /* fp32 [M, C] (row stride ldx) -> bf16 hi / lo planes [M, ldp] (ldp % 32 == 0, columns C..ldp-1 zero). */
 int ffsr_split_planes(const float* x, int ldx, void* hi, void* lo, int ldp, long long M, int C, void* stream);
 

@@ -1,0 +1,145 @@
+"""ffsr_tok_chain_f32 (token-stationary fused chains) against float64 torch: the Swin Mlp with its LayerNorm and residual
+(drct_arch.py:77-95, :405-407), GRL's post-norm form (mixed_attn_block_efficient.py:543-554) and NAFBlock's gated second half
+(nafnet_arch.py:125-131).  Tolerance: the split-bf16 products carry ~1e-5 relative error per GEMM (north_star: 1e-3)."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def mod(name):
+    return importlib.import_module("image-super-resolution_amd." + name)
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel(got, want):
+    return (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-20)
+
+
+@pytest.mark.parametrize("K,H,M,waves", [(180, 360, 1000, 8), (180, 360, 5000, 4), (212, 424, 777, 8), (244, 488, 2048, 4),
+                                         (276, 276, 1500, 8), (308, 308, 4096 + 16, 8), (180, 360, 352 * 512 + 40, 8)])
+def test_swin_mlp_prenorm_residual(K, H, M, waves, monkeypatch):
+    """x + fc2(GELU(fc1(LayerNorm(x)))) on a channel-slice view of a wider buffer (DRCT's dense-concat buffer)."""
+    ops = mod("ops")
+    monkeypatch.setattr(ops, "TOK_WAVES", waves)
+    g = gen(K + M)
+    wide = torch.randn(M, 308, generator=g) * 1.5 + 0.3
+    x = wide[:, :K]
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    w1, b1 = torch.randn(H, K, generator=g) / K ** 0.5, torch.randn(H, generator=g) * 0.1
+    w2, b2 = torch.randn(K, H, generator=g) / H ** 0.5, torch.randn(K, generator=g) * 0.1
+    xd = x.double()
+    n = F.layer_norm(xd, (K,), gamma.double(), beta.double(), 1e-5)
+    want = xd + F.linear(F.gelu(F.linear(n, w1.double(), b1.double())), w2.double(), b2.double())
+    tc = ops.pack_tok_chain(w1, b1, w2, b2, DEV, mode=0, ln=(gamma, beta), eps=1e-5)
+    xg = wide.to(DEV)[:, :K]
+    got = ops.tok_chain(xg, tc, res=xg)
+    assert tuple(got.shape) == (M, K)
+    assert rel(got, want) < 3e-5
+    # the output may also land in a channel slice of a wider buffer
+    buf = torch.full((M, 308), 7.0, device=DEV)
+    ops.tok_chain(xg, tc, res=xg, out=buf[:, :K])
+    assert torch.equal(buf[:, :K], got) and bool((buf[:, K:] == 7.0).all())
+
+
+@pytest.mark.parametrize("M", [640, 1027])
+def test_grl_mlp_postnorm_planes(M):
+    """y + LayerNorm(fc2(GELU(fc1(y)))) with fp32 and bf16-plane outputs (hi + lo == fp32 to 2^-17, pad columns zero)."""
+    ops = mod("ops")
+    K, H = 180, 360
+    g = gen(M)
+    y = torch.randn(M, K, generator=g)
+    w1, b1 = torch.randn(H, K, generator=g) / K ** 0.5, torch.randn(H, generator=g) * 0.1
+    w2, b2 = torch.randn(K, H, generator=g) / H ** 0.5, torch.randn(K, generator=g) * 0.1
+    g2, be2 = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    yd = y.double()
+    m = F.linear(F.gelu(F.linear(yd, w1.double(), b1.double())), w2.double(), b2.double())
+    want = yd + F.layer_norm(m, (K,), g2.double(), be2.double(), 1e-5)
+    tc = ops.pack_tok_chain(w1, b1, w2, b2, DEV, mode=0)
+    yg = y.to(DEV)
+    got, pl = ops.tok_chain(yg, tc, post_ln=(g2.to(DEV), be2.to(DEV)), res2=yg, out_planes=True)
+    assert rel(got, want) < 3e-5
+    back = pl.buf[0].float() + pl.buf[1].float()
+    assert pl.Cp == 192 and bool((back[:, K:] == 0).all())
+    assert (back[:, :K] - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item()
+    only = ops.tok_chain(yg, tc, post_ln=(g2.to(DEV), be2.to(DEV)), res2=yg, out_planes=True, want_f32=False)
+    assert torch.equal(only.buf, pl.buf)
+
+
+@pytest.mark.parametrize("c,M", [(64, 3000), (128, 1111)])
+def test_nafnet_gated_half(c, M):
+    """y + gamma * conv5(SimpleGate(conv4(LayerNorm2d(y)))) per pixel (nafnet_arch.py:125-131; eps 1e-6)."""
+    ops = mod("ops")
+    g = gen(c + M)
+    y = torch.randn(M, c, generator=g) * 2.0
+    ln_w, ln_b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    w4, b4 = torch.randn(2 * c, c, generator=g) / c ** 0.5, torch.randn(2 * c, generator=g) * 0.1
+    w5, b5 = torch.randn(c, c, generator=g) / c ** 0.5, torch.randn(c, generator=g) * 0.1
+    gam = torch.randn(c, generator=g) * 0.3
+    yd = y.double()
+    t = F.linear(F.layer_norm(yd, (c,), ln_w.double(), ln_b.double(), 1e-6), w4.double(), b4.double())
+    want = yd + F.linear(t[:, :c] * t[:, c:], w5.double(), b5.double()) * gam.double()
+    tc = ops.pack_tok_chain(w4, b4, w5, b5, DEV, mode=1, ln=(ln_w, ln_b), eps=1e-6)
+    yg = y.to(DEV)
+    got = ops.tok_chain(yg, tc, res=yg, cvec=gam.to(DEV))
+    assert rel(got, want) < 5e-5
+
+
+def test_gelu_fast_matches_erf_gelu():
+    """the kernel's GELU (erfc by Abramowitz-Stegun 7.1.26) against torch's exact-erf GELU through an identity chain:
+    W1 = I (K = 64 -> hidden 64 via the gate-free mode is not available, so use mode 0 with K = N = 180 and W2 = I)."""
+    ops = mod("ops")
+    K = 180
+    x = torch.linspace(-9.0, 9.0, 1024 * K).reshape(1024, K)
+    eye = torch.eye(K)
+    tc = ops.pack_tok_chain(eye, None, eye, None, DEV, mode=0)
+    got = ops.tok_chain(x.to(DEV), tc).cpu()
+    want = F.gelu(x.double())
+    # identity weights are exact in bf16; the input and the hidden value are carried as bf16 hi + lo (2^-17 relative each);
+    # the approximation itself adds <= 1.5e-7 * |x| / 2
+    err = (got.double() - want).abs()
+    assert (err - 2.0 ** -15 * want.abs()).max().item() < 1e-6
+    assert err[(x.abs() < 1.0)].max().item() < 1e-5
+
+
+@pytest.mark.parametrize("K,N,M,ln,bias,act", [(180, 540, 1000, True, True, 0), (308, 924, 2051, True, True, 0), (180, 720, 4099, True, False, 0),
+                                               (64, 128, 3333, True, True, 0), (128, 256, 700, True, True, 0), (244, 32, 1500, False, True, 3),
+                                               (212, 636, 352 * 512 + 8, True, True, 0), (276, 180, 900, False, True, 1)])
+def test_tok_gemm_with_layernorm_prologue(K, N, M, ln, bias, act):
+    """ffsr_tok_gemm_f32: act(W LayerNorm(x) + b) -- norm1 + qkv (drct_arch.py:385-388, :166), ln_1 + in_proj
+    (mambair_arch.py:417, :238), norm1 + conv1 (nafnet_arch.py:113-115) and the LeakyReLU(0.2) adjust convolutions writing a
+    channel slice of the dense-concat buffer (drct_arch.py:292-301)."""
+    ops = mod("ops")
+    g = gen(K * N + M)
+    wide = torch.randn(M, 308, generator=g) * 1.5 + 0.2
+    x = wide[:, :K]
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1 if bias else None
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    xd = x.double()
+    n = F.layer_norm(xd, (K,), gamma.double(), beta.double(), 1e-5) if ln else xd
+    want = F.linear(n, w.double(), None if b is None else b.double())
+    if act == 3:
+        want = F.leaky_relu(want, 0.2)
+    elif act == 1:
+        want = F.gelu(want)
+    tg = ops.pack_tok_gemm(w, b, DEV, ln=(gamma, beta) if ln else None)
+    xg = wide.to(DEV)[:, :K]
+    if N == 32:       # into a slice of a wider buffer, the rest untouched
+        buf = torch.full((M, 308), 7.0, device=DEV)
+        ops.tok_gemm(xg, tg, act=act, slope=0.2, out=buf[:, K:K + N])
+        got = buf[:, K:K + N]
+        assert bool((buf[:, :K] == 7.0).all()) and bool((buf[:, K + N:] == 7.0).all())
+    else:
+        got, pl = ops.tok_gemm(xg, tg, act=act, slope=0.2, out_planes=True)
+        back = pl.buf[0].float() + pl.buf[1].float()
+        assert bool((back[:, N:] == 0).all())
+        assert (back[:, :N] - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item()
+    assert rel(got, want) < 3e-5
