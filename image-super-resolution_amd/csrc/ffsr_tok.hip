@@ -25,84 +25,9 @@
 //   * the epilogue (bias, column scale, residual, optional LayerNorm of the output row + second residual, fp32 and / or
 //     bf16-plane stores) works per lane on 4 consecutive columns: 16-byte fp32 stores, 8-byte plane stores.
 // HBM traffic of a Swin MLP block: read x once, write out once.
-#include "ffsr_common.h"
-#include <type_traits>
+#include "ffsr_tok_common.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-struct TokArgs {
-  const float* x;            // [M, ldx] fp32 rows, K channels used
-  const unsigned char* w1;   // fragment-major bf16 hi / lo of W1': [steps][G tiles][KS1][2][64 lanes][8]
-  const float* b1;           // [steps * G * 16] hidden bias in packed tile order (zero padded)
-  const unsigned char* w2;   // [steps][NT2][2][64][8], k slots in accumulator order, rows in the lane-column order
-  const float* b2;           // [N] or null
-  const float* cvec;         // [N] or null: column scale of (y + b2)
-  const float* res;          // [M, ldr] or null: added after the column scale (scaled by rscale * rvec[n])
-  const float* rvec;         // [N] or null
-  const float* g2;           // [N] post-LayerNorm weight or null (no post-LN)
-  const float* be2;          // [N] post-LayerNorm bias
-  const float* res2;         // [M, ldr2] or null: added after the post-LN
-  float* out;                // [M, ldo] or null
-  unsigned short* o_hi;      // planes [M, ldp] or null
-  unsigned short* o_lo;
-  int ldx, ldr, ldr2, ldo, ldp;
-  int M, K, N, steps;
-  int pre_ln;
-  int res_is_x;              // res == x (same rows, same stride), no column scale: the accumulators start from the input row
-  float eps1, eps2, cscale, rscale;
-  int act;                   // MODE 2: epilogue activation (FfsrAct)
-  float slope;
-};
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  static_assert(N >= 0 && N <= 63, "vmcnt");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// tools/tok_ablate.sh builds this file with -DFFSR_TOK_ABL=<bits> (timing-only diagnostics, results are wrong):
-// 1 no activation math, 2 no fragment reads from LDS, 4 no barriers / waits, 8 no LDS-DMA fills, 16 no MFMAs
-#ifndef FFSR_TOK_ABL
-#define FFSR_TOK_ABL 0
-#endif
-__device__ __forceinline__ floatx4 mfma16(bf16x8 a, bf16x8 b, floatx4 c) {
-#if FFSR_TOK_ABL & 16
-  c[0] += __builtin_bit_cast(floatx4, a)[0] * __builtin_bit_cast(floatx4, b)[0];
-  return c;
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-#endif
-}
-
-// erfc(|x|) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of an fp32 rounding of erf itself) -- one rcp,
-// one exp2, seven FMAs: the activation runs between the two GEMMs of a wave, where ocml's erff (~40 instructions with
-// branches) would cost as much issue time as the MFMAs it sits between.
-//   gelu(v) = 0.5 v (1 + erf(v / sqrt 2)) = v >= 0 ? v - 0.5 v E : 0.5 v E,   E = erfc(|v| / sqrt 2)   (no cancellation)
-__device__ __forceinline__ float gelu_fast(float v) {
-#if FFSR_TOK_ABL & 1
-  return v;
-#endif
-  const float ax = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
-  const float hE = 0.5f * v * (pl * t * e);     // 0.5 v erfc(|x|)
-  return v >= 0.f ? v - hE : hE;
-}
-
-// 4 floats -> 4 bf16 hi (2 registers) + 4 bf16 lo
-__device__ __forceinline__ void split4(const floatx4 v, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
-  ffsr_split2(v[0], v[1], h0, l0);
-  ffsr_split2(v[2], v[3], h1, l1);
-}
 
 // The wave's 16 rows, fp32, in operand order: lane (token l & 15, q = l >> 4) holds columns 32 s + 8 q + 4 h + 0..3.
 template <int KS1>
