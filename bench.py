@@ -44,7 +44,7 @@ def synth_lr(seed, h, w, b=1):
     return torch.floor(x * 256).clamp(0, 255) / 255.0
 
 
-def cpu_baseline(weights, naf_cfg=None, tiles=5):
+def cpu_baseline(weights, naf_cfg=None, tiles=5, full=False):
     """Oracle (torch-CPU port of the reference path) on 64x64 tiles, one untimed warm-up tile then `tiles` timed ones
     (the reference loop is batch 1: io.py:330-345); returns the cpu_baseline object."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -66,12 +66,26 @@ def cpu_baseline(weights, naf_cfg=None, tiles=5):
             if i > 0:
                 dt += time.perf_counter() - t0
                 mp += out.shape[-1] * out.shape[-2] / 1e6
-    return {"value": mp / dt, "unit": "output MP/s", "cores": cores, "kind": "port",
-            "sample": f"{tiles} x 64x64 LR tiles -> 256x256 ({mp:.3f} MP), 4 experts + fusion, {dt:.1f} s of CPU work after one warm-up tile; "
-                      f"{cores} threads = the box's CPU share for one GPU ({os.cpu_count()} logical cores visible)"}
+    out = {"value": mp / dt, "unit": "output MP/s", "cores": cores, "kind": "port",
+           "cores_visible": os.cpu_count(), "cores_granted": cores,
+           "sample": f"{tiles} x 64x64 LR tiles -> 256x256 ({mp:.3f} MP), 4 experts + fusion, {dt:.1f} s of CPU work after one warm-up tile; "
+                     f"{cores} threads = the box's CPU share for one GPU ({os.cpu_count()} logical cores visible)",
+           # the tile sample flatters the CPU (cache-resident maps): one real 340x510 oracle pass on the same 16-core share
+           # measured 292 s = 0.0095 MP/s (profiles/r03_cpu_baseline_at_metric_size.md; re-measure with --cpu-full)
+           "at_metric_size": {"value": 0.0095, "unit": "output MP/s", "seconds_per_image": 292.0, "measured": "round 2, GPU box, "
+                              "16 threads, tests/test_gpu_baseline_configs.py::test_full_size_340x510_vs_oracle", "live": False}}
+    if full:
+        lr = synth_lr(1234, H_LR, W_LR)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            o = pipeline.process_image(weights, lr, naf_cfg=naf_cfg, scan_fn=selective_scan_c)
+            dt_f = time.perf_counter() - t0
+        out["at_metric_size"] = {"value": o.shape[-1] * o.shape[-2] / 1e6 / dt_f, "unit": "output MP/s", "seconds_per_image": dt_f,
+                                 "measured": f"this run, {cores} threads, one {W_LR}x{H_LR} image, no warm-up", "live": True}
+    return out
 
 
-def train_bench(args):
+def train_measure(args, steps, warmup, cpu=True, quiet=False):
     """BASELINE config 5 (`--config train`): ONE cached-feature training step of the fusion network per "step" --
     forward_with_precomputed in train mode on a batch of 32 cached 64x64 LR patches (seeded expert images / features
     resident in HBM), L1 loss after clamp, backward through all 1.43 M parameters, clip_grad_norm_(1.0), AdamW(2e-4,
@@ -99,13 +113,14 @@ def train_bench(args):
     hr = E.nchw_to_map(torch.rand(B, 3, 4 * h, 4 * w, generator=g), device)
     lrm = E.nchw_to_map(lr, device)
     T0 = time.perf_counter()
-    for i in range(args.warmup):
+    for i in range(warmup):
         tr.step(lrm, hr, imgs, feats)
         torch.cuda.synchronize(device)
-        print(f"[bench +{time.perf_counter() - T0:6.1f}s] warm-up training step {i} done", file=sys.stderr, flush=True)
+        if not quiet:
+            print(f"[bench +{time.perf_counter() - T0:6.1f}s] warm-up training step {i} done", file=sys.stderr, flush=True)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = tr.step(lrm, hr, imgs, feats)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
@@ -113,18 +128,18 @@ def train_bench(args):
     tflop = 3 * B * (h * w / 4096.0) * 116.3e9 / 1e12
     peak = MFMA_F32_PEAK_TFLOPS if ops.GEMM_MODE == "f32" else MFMA_BF16_PEAK_TFLOPS / 3.0
     line = {"metric": f"cached-feature training steps/s (BASELINE config 5: {B} x {w}x{h} LR patches, fusion net fwd + bwd + AdamW)",
-            "value": args.steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (conv products as 3-term split-bf16 MFMA; weight gradients: split-bf16 MFMA for the wide 3x3 layers, exact fp32 elsewhere)",
             "data": "synthetic (seeded cached expert images / features / HR targets; random-init fusion weights)",
             "config": {"workload": f"train_epoch_cached step: forward_with_precomputed(train) + L1 + backward + clip + AdamW + EMA, "
                                    f"batch {B} of {w}x{h} LR patches -> {4 * w}x{4 * h}", "patches_per_step": B,
-                       "patches_per_s": B * args.steps / dt, "attention_dropout": 0.0},
+                       "patches_per_s": B * steps / dt, "attention_dropout": tr.net.attn_dropout},
             "gemm_mode": ops.GEMM_MODE, "final_loss": float(loss.item()),
-            "roofline": {"bound": "mfma", "achieved": tflop / (dt / args.steps), "peak": peak, "unit": "TFLOP/s",
-                         "frac": tflop / (dt / args.steps) / peak, "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": tflop / (dt / steps), "peak": peak, "unit": "TFLOP/s",
+                         "frac": tflop / (dt / steps) / peak, "traffic": None,
                          "note": "whole step: algorithmic 3 x forward FLOPs (SURVEY 8d) / step time, not a single kernel"}}
-    if not args.no_cpu_baseline:
+    if cpu and not args.no_cpu_baseline:
         # the same step on the host: the oracle's train-mode forward differentiated by torch autograd + torch.optim.AdamW, on a
         # bounded sample (2 of the 32 patches, one warm-up + 2 timed steps); reported in patches/s next to config.patches_per_s
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -153,7 +168,13 @@ def train_bench(args):
                                 "sample": f"2 timed steps on {nb} of the {B} patches after one warm-up step ({cdt:.1f} s of CPU work): "
                                           f"oracle train-mode forward + torch autograd + clip + torch.optim.AdamW"}
         line["gpu_over_cpu"] = line["config"]["patches_per_s"] / line["cpu_baseline"]["value"]
-    print(json.dumps(line))
+    del tr
+    torch.cuda.empty_cache()
+    return line
+
+
+def train_bench(args):
+    print(json.dumps(train_measure(args, args.steps, args.warmup)))
 
 
 def dry_run(args):
@@ -206,6 +227,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per step per GPU (BASELINE config 3 uses 16 x 64x64)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline: also time ONE real 340x510 oracle pass (~5 min of host time)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tile64 / train_step measurements after the headline one")
     ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=None, help="GEMM arithmetic (default: the engine's default)")
     ap.add_argument("--dry-run", action="store_true",
@@ -392,11 +415,40 @@ def main():
                            "hip_graph": bool(args.graph),
                            "small_experts": bool(args.small)},
                 "gemm_mode": ops.GEMM_MODE, "roofline": roofline}
+        default_geometry = (h, w) == (H_LR, W_LR) and args.batch == 1 and not args.small and not args.graph
+        if world == 1 and default_geometry and not args.no_extras:
+            # ---- north_star's second geometry and BASELINE config 5, measured in the same process after the headline
+            # (value / metric / config above are unaffected)
+            log("extras: 64x64 LR tile (batch 1, HIP-graph replay = the engine's default for small tiles) ...")
+            t64 = E.nchw_to_map(synth_lr(4321, 64, 64), device)
+            for _ in range(3):
+                eng.process(t64)
+            torch.cuda.synchronize(device)
+            n64 = 30
+            t1 = time.perf_counter()
+            for _ in range(n64):
+                o64 = eng.process(t64)
+            torch.cuda.synchronize(device)
+            ms64 = 1e3 * (time.perf_counter() - t1) / n64
+            tfl64 = 884.0e9 / 1e12                      # 215.8 MFLOP per LR pixel = 884 GFLOP per 64x64 tile
+            line["tile64"] = {"ms": ms64, "mp_s": 256 * 256 / 1e6 / (ms64 / 1e3), "tflops": tfl64 / (ms64 / 1e3),
+                              "frac": tfl64 / (ms64 / 1e3) / (MFMA_BF16_PEAK_TFLOPS / 3.0 if ops.GEMM_MODE != "f32" else MFMA_F32_PEAK_TFLOPS),
+                              "frac_of": "split-bf16 MFMA ceiling (2500 / 3 TFLOP/s)" if ops.GEMM_MODE != "f32" else "f32 MFMA peak",
+                              "workload": "one 64x64 LR tile -> 256x256, full 4-expert + fusion path, batch 1, graph replay",
+                              "steps": n64}
+            del eng
+            torch.cuda.empty_cache()
+            log("extras: BASELINE config 5, 3 training steps at B = 32 ...")
+            tl = train_measure(args, steps=3, warmup=1, cpu=False, quiet=True)
+            line["train_step"] = {"ms": tl["ms_per_step"], "patches_s": tl["config"]["patches_per_s"], "frac": tl["roofline"]["frac"],
+                                  "frac_of": "split-bf16 MFMA ceiling, algorithmic 3 x forward FLOPs", "steps": 3, "batch": 32,
+                                  "attention_dropout": tl["config"]["attention_dropout"], "final_loss": tl["final_loss"]}
         if world == 1 and not args.no_cpu_baseline:
             naf_cfg = dict(enc_blks=(1, 1, 1, 1), mid_blks=1, dec_blks=(1, 1, 1, 1)) if args.small else None
             log("cpu_baseline: oracle on 64x64 tiles ...")
-            line["cpu_baseline"] = cpu_baseline(weights, naf_cfg)
+            line["cpu_baseline"] = cpu_baseline(weights, naf_cfg, full=args.cpu_full)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            line["gpu_over_cpu_at_metric_size"] = value / line["cpu_baseline"]["at_metric_size"]["value"]
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

@@ -132,6 +132,7 @@ class Tape:
         self.device = torch.device(device)
         self._bw = []
         self.enabled = True
+        self.seed, self.step, self._draws = 0, 0, 0     # dropout draws: (seed, step, index of the draw within the step)
 
     # ------------------------------------------------------------------------------------------ plumbing
     def _rec(self, fn):
@@ -145,6 +146,10 @@ class Tape:
 
     def clear(self):
         self._bw.clear()
+
+    def new_step(self, step: int):
+        """start a forward pass: dropout masks of this pass are drawn from (seed, step, 0..)"""
+        self.step, self._draws = int(step), 0
 
     class _NoGrad:
         def __init__(self, tape):
@@ -512,8 +517,14 @@ class Tape:
         return y
 
     # ------------------------------------------------------------------------------------------ attention / fusion tails
-    def pixel_mha(self, qkv: Var, S, T, E, heads) -> Var:
-        y = Var(ops.pixel_mha(qkv.v, S, T, E, heads))
+    def pixel_mha(self, qkv: Var, S, T, E, heads, p_drop=0.0) -> Var:
+        """nn.MultiheadAttention's core; p_drop > 0: attention dropout, every call of a step draws its own mask (seed =
+        (tape seed, step, call index)) and the backward closure replays exactly that mask"""
+        seed = 0
+        if p_drop > 0:
+            seed = (self.seed * 1000003 + self.step) * 4099 + self._draws
+            self._draws += 1
+        y = Var(ops.pixel_mha(qkv.v, S, T, E, heads, p_drop=p_drop, seed=seed))
 
         def bw():
             if y.g is None:
@@ -521,7 +532,7 @@ class Tape:
             dq = torch.empty(S * T, 3 * E, device=self.device)
             scratch = torch.empty(2 * S * heads * T * T, device=self.device)
             hip.call("ffsr_pixel_mha_bwd_f32", _ptr(qkv.v), _mat(qkv.v)[3], _ptr(y.g), _mat(y.g)[3], _ptr(dq), 3 * E, _ptr(scratch),
-                     S, T, E, heads, _stream())
+                     float(p_drop), int(seed), S, T, E, heads, _stream())
             self.acc(qkv, dq)
         self._rec(bw)
         return y

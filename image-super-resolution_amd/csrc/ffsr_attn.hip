@@ -715,10 +715,12 @@ __global__ __launch_bounds__(64) void grl_stripe_kernel(const float* __restrict_
 
 // --------------------------------------------------------------------------------------------------------------
 // (3) per-pixel MHA: qkv [S*T, 3E] (q | k | v, heads of 16) -> out [S*T, E].  thread = (sequence, token, head)
+// drop_thr > 0 (training): attention dropout -- probability (seq, head, t, j) is kept iff ffsr_rng_u32(seed, its index) >=
+// drop_thr and scaled by keep_scale = 1 / (1 - p)  (nn.MultiheadAttention(dropout=0.1), large_kernel_attention.py:196,298)
 // --------------------------------------------------------------------------------------------------------------
 template <int T>
 __global__ void pixel_mha_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo, long long S,
-                                 int E, int heads) {
+                                 int E, int heads, unsigned drop_thr, float keep_scale, unsigned long long seed) {
   constexpr int HD = 16;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= S * T * heads) return;
@@ -760,7 +762,11 @@ __global__ void pixel_mha_kernel(const float* __restrict__ qkv, int ldq, float* 
 #pragma unroll
   for (int j = 0; j < T; ++j) {
     const float* vrow = qkv + (seq * T + j) * ldq + 2 * E + h * HD;
-    const float pj = s[j] * inv;
+    float pj = s[j] * inv;
+    if (drop_thr) {
+      const unsigned long long e = (((unsigned long long)seq * heads + h) * T + (unsigned long long)(st - seq * T)) * T + j;
+      pj = ffsr_rng_u32(seed, e) >= drop_thr ? pj * keep_scale : 0.f;
+    }
 #pragma unroll
     for (int d = 0; d < HD; d += 4) {
       floatx4 v = *reinterpret_cast<const floatx4*>(vrow + d);
@@ -881,14 +887,18 @@ extern "C" int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, con
 }
 
 extern "C" int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo, long long S, int T, int E, int heads,
+                                  float p_drop, long long seed,
                                   void* stream) {
   FFSR_CHECK(qkv && out && S > 0 && heads > 0 && E == heads * 16 && (ldq % 4) == 0 && (ldo % 4) == 0);
   FFSR_CHECK(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0);
+  FFSR_CHECK(p_drop >= 0.f && p_drop < 1.f);
+  const unsigned thr = ffsr_drop_threshold(p_drop);
+  const float ks = 1.0f / (1.0f - p_drop);
   long long n = S * T * heads;
   dim3 grid((unsigned)((n + 255) / 256));
   switch (T) {
-    case 9: FFSR_LAUNCH(pixel_mha_kernel<9>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
-    case 4: FFSR_LAUNCH(pixel_mha_kernel<4>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads); break;
+    case 9: FFSR_LAUNCH(pixel_mha_kernel<9>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads, thr, ks, (unsigned long long)seed); break;
+    case 4: FFSR_LAUNCH(pixel_mha_kernel<4>, grid, dim3(256), 0, ST, qkv, ldq, out, ldo, S, E, heads, thr, ks, (unsigned long long)seed); break;
     default: return FFSR_EINVAL;
   }
   return ffsr_launch_status();

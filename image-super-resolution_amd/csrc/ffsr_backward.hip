@@ -560,9 +560,12 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dout, int ldo, flo
 // qkv [S*T, 3E] (q | k | v, heads of 16), dout [S*T, E].  Kernel A: thread = (sequence, head, query t): recomputes the
 // softmax row P[t, :], writes dq[t] and the rows P[t, :], dS[t, :] (dS = P (dP - sum P dP), dP = dO V^T) to scratch;
 // kernel B: thread = (sequence, head, key j): dk[j] = scale sum_t dS[t, j] q[t],  dv[j] = sum_t P[t, j] dO[t].
+// Attention dropout (drop_thr > 0): the forward pass used P' = P * m, m[t, j] = keep ? 1 / (1 - p) : 0 regenerated here from the
+// same (seed, element index); then dP = (dO V^T) * m, dS = P (dP - sum P dP) and dv uses P'.
 template <int T>
 __global__ void pixel_mha_bwd_a_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int ldo,
-                                       float* __restrict__ dqkv, int lddq, float* __restrict__ scratch, long long S, int E, int heads) {
+                                       float* __restrict__ dqkv, int lddq, float* __restrict__ scratch, long long S, int E, int heads,
+                                       unsigned drop_thr, float keep_scale, unsigned long long seed) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= S * heads * T) return;
   const int t = (int)(idx % T);
@@ -588,6 +591,16 @@ __global__ void pixel_mha_bwd_a_kernel(const float* __restrict__ qkv, int ldq, c
   float den = 0.f;
 #pragma unroll
   for (int j = 0; j < T; ++j) p[j] = expf(p[j] - mx), den += p[j];
+  float mk[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    mk[j] = 1.f;
+    if (drop_thr) {
+      const unsigned long long e = (((unsigned long long)s * heads + h) * T + t) * T + j;
+      mk[j] = ffsr_rng_u32(seed, e) >= drop_thr ? keep_scale : 0.f;
+    }
+    dp[j] *= mk[j];
+  }
   float dot = 0.f;
 #pragma unroll
   for (int j = 0; j < T; ++j) p[j] /= den, dot = fmaf(p[j], dp[j], dot);
@@ -598,7 +611,7 @@ __global__ void pixel_mha_bwd_a_kernel(const float* __restrict__ qkv, int ldq, c
 #pragma unroll
   for (int j = 0; j < T; ++j) {
     const float ds = p[j] * (dp[j] - dot);
-    sc[j] = p[j], sc[T + j] = ds;
+    sc[j] = p[j] * mk[j], sc[T + j] = ds;
     const float* kj = base + (size_t)j * ldq + E;
 #pragma unroll
     for (int d = 0; d < 16; ++d) dq[d] = fmaf(ds * scale, kj[d], dq[d]);
@@ -948,15 +961,19 @@ extern "C" int ffsr_avgpool2_bwd_f32(const float* dout, int ldo, float* din, int
 
 // backward of ffsr_pixel_mha_f32 (eval-mode attention core, dropout 0): dqkv [S*T, 3E]; scratch: 2 * S * heads * T * T floats
 extern "C" int ffsr_pixel_mha_bwd_f32(const float* qkv, int ldq, const float* dout, int ldo, float* dqkv, int lddq, float* scratch,
+                                      float p_drop, long long seed,
                                       long long S, int T, int E, int heads, void* stream) {
   FFSR_CHECK(qkv && dout && dqkv && scratch && S > 0 && (T == 9 || T == 4) && heads * 16 == E && ldq >= 3 * E && ldo >= E &&
              lddq >= 3 * E);
+  FFSR_CHECK(p_drop >= 0.f && p_drop < 1.f);
+  const unsigned thr = ffsr_drop_threshold(p_drop);
+  const float ks = 1.0f / (1.0f - p_drop);
   const int g = grid_for(S * heads * T);
   if (T == 9) {
-    FFSR_LAUNCH(pixel_mha_bwd_a_kernel<9>, dim3(g), dim3(RB), 0, ST, qkv, ldq, dout, ldo, dqkv, lddq, scratch, S, E, heads);
+    FFSR_LAUNCH(pixel_mha_bwd_a_kernel<9>, dim3(g), dim3(RB), 0, ST, qkv, ldq, dout, ldo, dqkv, lddq, scratch, S, E, heads, thr, ks, (unsigned long long)seed);
     FFSR_LAUNCH(pixel_mha_bwd_b_kernel<9>, dim3(g), dim3(RB), 0, ST, qkv, ldq, dout, ldo, dqkv, lddq, scratch, S, E, heads);
   } else {
-    FFSR_LAUNCH(pixel_mha_bwd_a_kernel<4>, dim3(g), dim3(RB), 0, ST, qkv, ldq, dout, ldo, dqkv, lddq, scratch, S, E, heads);
+    FFSR_LAUNCH(pixel_mha_bwd_a_kernel<4>, dim3(g), dim3(RB), 0, ST, qkv, ldq, dout, ldo, dqkv, lddq, scratch, S, E, heads, thr, ks, (unsigned long long)seed);
     FFSR_LAUNCH(pixel_mha_bwd_b_kernel<4>, dim3(g), dim3(RB), 0, ST, qkv, ldq, dout, ldo, dqkv, lddq, scratch, S, E, heads);
   }
   return ffsr_launch_status();

@@ -70,6 +70,23 @@ __device__ __forceinline__ float ffsr_act(float v, int act, float slope) {
   }
 }
 
+// Counter-based random bits for dropout masks: mask element `idx` of the draw identified by `seed` -> 32 uniform bits
+// (splitmix64 finaliser of seed * golden + idx; stateless, so the backward pass regenerates the forward pass's mask from the
+// same (seed, idx)).  keep = bits >= threshold, threshold = p * 2^32.
+__device__ __forceinline__ unsigned ffsr_rng_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + idx;
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32);
+}
+static inline unsigned ffsr_drop_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (unsigned)t);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -103,10 +103,22 @@ class Engine:
             t.record_stream(main)
         return (imgs, feats, tuple(pre)) if with_lr_phases else (imgs, feats)
 
-    def process(self, lr, lane=None):
+    # tiles of at most this many LR pixels (batch 1) are launch-bound when enqueued eagerly (~3.5 k launches, ~40 ms of host
+    # time per 64x64 tile against ~15 ms of GPU time): process() replays them from a captured HIP graph by default
+    GRAPH_MAX_PIXELS = 128 * 128
+
+    def process(self, lr, lane=None, graph=None):
         """lr [B,h,w,3] float map in [0,1] -> SR map [B,4h,4w,3] in [0,1].
         lane None: runs on the caller's current stream.  lane 0 / 1: runs asynchronously on that lane's own streams
-        (the caller's stream is only waited for at the start); the caller must ``join()`` before reading the result."""
+        (the caller's stream is only waited for at the start); the caller must ``join()`` before reading the result.
+        graph None: small single tiles (<= 128x128 LR pixels) are replayed from a HIP graph captured once per shape (the result
+        is copied out of the graph's static buffer, so it stays valid across calls); True / False force it."""
+        B, h, w, _ = lr.shape
+        if graph is None:
+            graph = (lane is None and B == 1 and h * w <= self.GRAPH_MAX_PIXELS and self.concurrent_experts
+                     and os.environ.get("FFSR_GRAPH_SMALL", "1") != "0" and not torch.cuda.is_current_stream_capturing())
+        if graph:
+            return self.process_graphed(lr).clone()
         with torch.cuda.device(self.device):
             if lane is None:
                 imgs, feats, pre = self.run_experts(lr, with_lr_phases=True)
@@ -131,11 +143,11 @@ class Engine:
                 side = torch.cuda.Stream(self.device)            # warm-up off the capture: first-launch attributes,
                 side.wait_stream(torch.cuda.current_stream())    # lazily packed constants and allocator pools settle
                 with torch.cuda.stream(side):
-                    self.process(static_in)
+                    self.process(static_in, graph=False)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    static_out = self.process(static_in)
+                    static_out = self.process(static_in, graph=False)
                 ent = self._graphs[key] = (graph, static_in, static_out)
             graph, static_in, static_out = ent
             static_in.copy_(lr)

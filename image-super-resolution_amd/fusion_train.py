@@ -9,8 +9,11 @@ train and eval mode that the reference has and this file reproduces:
   (large_kernel_attention.py:84,128,131,247-251,404);
 * no clamp after the collaborative modulation (large_kernel_attention.py:420-423) and none on the final image
   (enhanced_fusion_v2.py:792-795); the clamp inside the Laplacian refinement stays (edge_enhancement.py:260);
-* nn.MultiheadAttention's attention dropout (p = 0.1, :196,298) is DISABLED here, as SURVEY 8(d) allows for config 5: the
-  reference's dropout mask comes from torch's Philox stream, which a from-scratch engine cannot reproduce bit-for-bit.
+* nn.MultiheadAttention's attention dropout (p = 0.1, :196,298): ``attn_dropout`` (default 0.1, the reference's value) drops
+  attention probabilities with a counter-based mask of this engine's own (mask = f(seed, step, draw, element index), replayed by
+  the backward kernel).  The reference's mask comes from torch's Philox stream, which a from-scratch engine cannot reproduce
+  bit-for-bit: with p > 0 the step is statistically, not bit-wise, the reference's ("parity unpinned"); ``attn_dropout=0`` is the
+  configuration the golden training fixture pins (SURVEY 8(d) allows dropout off for config 5).
 
 Same GPU-first layout as fusion.py (token tensors instead of stack / permute copies, concatenations as channel slices, the
 1x1 128->32 modulation conv applied before the bilinear upsample).  Nothing is folded into the weights here: every
@@ -73,17 +76,18 @@ class _MHA:
         self.E = self.out.N
         self.convs = [self.inp, self.out]
 
-    def __call__(self, t: Tape, normed: Var, S, T):
+    def __call__(self, t: Tape, normed: Var, S, T, p_drop=0.0):
         qkv = t.linear(normed, self.inp)
-        return t.linear(t.pixel_mha(qkv, S, T, self.E, self.heads), self.out)
+        return t.linear(t.pixel_mha(qkv, S, T, self.E, self.heads, p_drop=p_drop), self.out)
 
 
 class FusionTrainNet:
     """params: name -> Param (views into the optimiser's flat parameter / gradient buffers); buffers: name -> device tensor
     (BatchNorm running statistics are updated in place, the rest are constants)."""
 
-    def __init__(self, params: Dict[str, Param], buffers: Dict[str, torch.Tensor], device, scale=4):
+    def __init__(self, params: Dict[str, Param], buffers: Dict[str, torch.Tensor], device, scale=4, attn_dropout=0.1):
         self.device, self.scale = torch.device(device), scale
+        self.attn_dropout = float(attn_dropout)
         P, buf = params, buffers
         self.P = P
         cp = lambda k, **kw: ConvP(P[k + ".weight"], P.get(k + ".bias"), device, **kw)
@@ -252,7 +256,7 @@ class FusionTrainNet:
         t._rec(rows_bw)
         proj = t.linear(rows, self.band_proj)                                                      # [Pn*9, 64]
         nrm = t.layernorm(proj, P["cross_band.norm.weight"], P["cross_band.norm.bias"])
-        attn = t.add(self.cb_mha(t, nrm, Pn, 9), proj)
+        attn = t.add(self.cb_mha(t, nrm, Pn, 9, self.attn_dropout), proj)
         feats = t.split(attn, [tok(i, 9, B, h, w) for i in range(9)])
         routing = None
         for i in range(9):           # the shared block sees the bands in order: 9 BatchNorm running-statistics updates
@@ -275,7 +279,7 @@ class FusionTrainNet:
         al = [t.conv(Var(feats[n], req=False), self.align[n], out=sel[e](st)) for e, n in enumerate(EXPERTS)]
         stv = t.join(al, st, sel)
         n1 = t.layernorm(stv, P["collaborative.norm1.weight"], P["collaborative.norm1.bias"])
-        s1 = t.add(stv, self.co_mha(t, n1, Pn, 4))
+        s1 = t.add(stv, self.co_mha(t, n1, Pn, 4, self.attn_dropout))
         n2 = t.layernorm(s1, P["collaborative.norm2.weight"], P["collaborative.norm2.bias"])
         s2 = t.add(s1, t.linear(t.linear(n2, self.co_f0, act=ACT_GELU), self.co_f2))
         parts = t.split(s2, sel)

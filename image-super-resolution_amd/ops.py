@@ -818,10 +818,12 @@ def grl_stripe_attn(qkv, col0, anchor, bias1T, bias2T, logit1, logit2, out, ocol
     return out
 
 
-def pixel_mha(qkv, S, T, E, heads, out=None):
+def pixel_mha(qkv, S, T, E, heads, out=None, p_drop=0.0, seed=0):
+    """p_drop > 0 (training): attention dropout with the counter-based mask of draw `seed` (see include/ffsr.h)"""
     if out is None:
         out = torch.empty(S * T, E, device=qkv.device)
-    hip.call("ffsr_pixel_mha_f32", _ptr(qkv), _mat(qkv)[3], _ptr(out), _mat(out)[3], S, T, E, heads, _stream())
+    hip.call("ffsr_pixel_mha_f32", _ptr(qkv), _mat(qkv)[3], _ptr(out), _mat(out)[3], S, T, E, heads, float(p_drop), int(seed),
+             _stream())
     return out
 
 

@@ -94,10 +94,12 @@ class FusionTrainer:
         loss.backward()                                                        # autograd.Tape.backward()
         clip_grad_norm_ / optimizer.step() / zero_grad / ema.update            # FusionOptimizer.step (every accumulation_steps)
 
-    ``state_dict``: the fusion network's (parameters AND buffers; reference keys).  Attention dropout is off (see
-    fusion_train.py).  No CPU fallback."""
+    ``state_dict``: the fusion network's (parameters AND buffers; reference keys).  attn_dropout: p of the two
+    nn.MultiheadAttention's attention dropout (default 0.1 as the reference; 0 = the fixture-pinned configuration), seed: of
+    its counter-based masks (see fusion_train.py).  No CPU fallback."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device, scale=4, accumulation_steps=1, **opt_kwargs):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, scale=4, accumulation_steps=1, attn_dropout=0.1, seed=0,
+                 **opt_kwargs):
         from . import autograd, fusion_train
         self.device = torch.device(device)
         self.accumulation_steps = accumulation_steps
@@ -113,8 +115,10 @@ class FusionTrainer:
                             if not fusion_train.is_parameter(k)}
             pv, gv = self.opt.views(), self.opt.views(self.opt.grad)
             self.params = {k: autograd.Param(k, pv[k], gv[k]) for k in pv}
-            self.net = fusion_train.FusionTrainNet(self.params, self.buffers, self.device, scale)
+            self.net = fusion_train.FusionTrainNet(self.params, self.buffers, self.device, scale, attn_dropout=attn_dropout)
             self.tape = autograd.Tape(self.device)
+            self.tape.seed = int(seed)
+        self.forward_count = 0
         self.micro = 0
 
     def zero_grad(self):
@@ -125,6 +129,8 @@ class FusionTrainer:
         Accumulates d loss / d parameters into the flat gradient buffer; returns (loss [1] device tensor, sr map)."""
         with torch.cuda.device(self.device), torch.no_grad():
             self.tape.clear()      # closures left behind by a forward / backward that raised must never be replayed
+            self.tape.new_step(self.forward_count)          # this pass's dropout draws
+            self.forward_count += 1
             try:
                 sr = self.net.forward(self.tape, lr, imgs, feats)
                 loss, g = l1_clamp_loss(sr.v, hr, self.accumulation_steps)

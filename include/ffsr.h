@@ -211,10 +211,15 @@ int ffsr_grl_stripe_attn_f32(const float* qkv, int ldq, int col0, const float* a
                              const float* bias2T, const float* logit1, const float* logit2, float* out, int ldo,
                              int ocol0, int B, int H, int W, int heads, int hd, void* stream);
 
-/* nn.MultiheadAttention core (eval) on S sequences of T tokens (T = 9 bands or 4 experts), heads of 16:
- * qkv [S*T, 3E] -> out [S*T, E].  Replaces large_kernel_attention.py:222-233, 385-396 (between in/out proj). */
-int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo, long long S, int T, int E, int heads,
-                       void* stream);
+/* nn.MultiheadAttention core on S sequences of T tokens (T = 9 bands or 4 experts), heads of 16:
+ * qkv [S*T, 3E] -> out [S*T, E].  Replaces large_kernel_attention.py:222-233, 385-396 (between in/out proj).
+ * p_drop = 0: eval mode.  p_drop in (0, 1) (training; the reference's two attentions use dropout = 0.1, :196, :298):
+ * attention-probability dropout with a counter-based mask -- element (sequence, head, query, key) of the draw `seed` is kept
+ * iff splitmix64(seed, element index) >> 32 >= p_drop * 2^32, kept probabilities are scaled by 1 / (1 - p_drop).  The mask is
+ * a pure function of (seed, index): ffsr_pixel_mha_bwd_f32 regenerates it from the same seed.  (Not torch's Philox stream:
+ * bit-parity with the reference's dropout mask is unpinned by construction.) */
+int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo, long long S, int T, int E, int heads, float p_drop,
+                       long long seed, void* stream);
 
 /* Four-direction selective scan with the dt projection fused (mamba_ssm selective_scan_fn as called at
  * mambair_arch.py:339-369 incl. the direction gather :343-344 and inverse scatter :365-369).
@@ -404,10 +409,10 @@ int ffsr_bilinear_bwd_f32(const float* dout, int ldo, float* din, int ldi, int B
 int ffsr_avgpool2_bwd_f32(const float* dout, int ldo, float* din, int ldi, int B, int H, int W, int C, int accumulate,
                           void* stream);
 
-/* Backward of ffsr_pixel_mha_f32 (attention dropout 0): dqkv [S*T, 3E].
+/* Backward of ffsr_pixel_mha_f32: dqkv [S*T, 3E]; p_drop / seed = the forward call's (the dropout mask is regenerated).
  * scratch: 2 * S * heads * T * T floats. */
 int ffsr_pixel_mha_bwd_f32(const float* qkv, int ldq, const float* dout, int ldo, float* dqkv, int lddq, float* scratch,
-                           long long S, int T, int E, int heads, void* stream);
+                           float p_drop, long long seed, long long S, int T, int E, int heads, void* stream);
 
 /* softmax over the C <= 8 channels of every row and its backward (F.softmax(freq_logits, dim=1), enhanced_fusion_v2.py:743). */
 int ffsr_softmax_c_f32(const float* x, int ldx, float* y, int ldy, long long M, int C, void* stream);

@@ -337,6 +337,54 @@ def test_pixel_mha_backward(T, E, heads):
     assert rel(qv.g, qt.grad) < 1e-4
 
 
+@pytest.mark.parametrize("T,E,heads", [(9, 64, 4), (4, 128, 8)])
+def test_pixel_mha_attention_dropout(T, E, heads):
+    """nn.MultiheadAttention(dropout=0.1) in train mode (large_kernel_attention.py:196,298): probabilities are dropped with a
+    counter-based mask.  Checked: the mask is {0, 1/(1-p)}-valued with a keep rate within 3 sigma of 1-p, is a function of the
+    seed only (same seed -> same output, other seed -> other mask, independent of the data), and the backward kernel
+    differentiates exactly the masked attention of the forward pass (torch autograd on the recovered, frozen mask).
+    Bit-parity with torch's Philox stream is unpinned by construction."""
+    A, ops = mod("autograd"), mod("ops")
+    p, S, g = 0.1, 900, gen(T + 100)
+    qkv = torch.randn(S * T, 3 * E, generator=g)
+    # recover the mask: V = one-hot of the key index in the first T dims of every head -> out[t, h, j] = P'[t, j]
+    probe = qkv.clone().reshape(S, T, 3, heads, 16)
+    probe[:, :, 2] = 0.0
+    for j in range(T):
+        probe[:, j, 2, :, j] = 1.0
+    probe = probe.reshape(S * T, 3 * E)
+    q, k = (probe.reshape(S, T, 3, heads, 16)[:, :, i].transpose(1, 2) for i in range(2))
+    P = ((q / 4.0) @ k.transpose(-2, -1)).softmax(-1)                                      # [S, heads, T, T]
+    out = ops.pixel_mha(probe.to(DEV), S, T, E, heads, p_drop=p, seed=0).cpu().reshape(S, T, heads, 16)[..., :T].permute(0, 2, 1, 3)
+    mask = out / P                                                                          # 0 or 1 / (1 - p)
+    kept = mask > 0.5
+    assert torch.allclose(mask[kept], torch.full_like(mask[kept], 1.0 / (1.0 - p)), rtol=1e-4)
+    assert float(mask[~kept].abs().max()) == 0.0
+    n = mask.numel()
+    assert abs(kept.float().mean().item() - (1 - p)) < 3.0 * (p * (1 - p) / n) ** 0.5
+    # a function of the seed, not of the data
+    again = ops.pixel_mha(probe.to(DEV), S, T, E, heads, p_drop=p, seed=0).cpu()
+    assert torch.equal(again.reshape(S, T, heads, 16)[..., :T].permute(0, 2, 1, 3), out)
+    other = ops.pixel_mha(probe.to(DEV), S, T, E, heads, p_drop=p, seed=1).cpu().reshape(S, T, heads, 16)[..., :T].permute(0, 2, 1, 3)
+    assert 0.1 < ((other > 0) != kept).float().mean().item() < 0.3                         # ~ 2 p (1 - p) = 0.18 of the entries differ
+    # forward on real data = masked attention; backward = its gradient
+    dy = torch.randn(S * T, E, generator=g)
+    qt = qkv.clone().requires_grad_(True)
+    q, k, v = (qt.reshape(S, T, 3, heads, 16)[:, :, i].transpose(1, 2) for i in range(3))
+    o = (((q / 4.0) @ k.transpose(-2, -1)).softmax(-1) * mask) @ v
+    want = o.transpose(1, 2).reshape(S * T, E)
+    want.backward(dy)
+    t = A.Tape(DEV)                      # seed 0, step 0, first draw -> the probe's seed 0
+    qv = A.Var(qkv.to(DEV))
+    y = t.pixel_mha(qv, S, T, E, heads, p_drop=p)
+    assert rel(y.v, want.detach()) < 1e-5
+    y.g = dy.to(DEV)
+    t.backward()
+    assert rel(qv.g, qt.grad) < 1e-4
+    # p = 0 stays the eval kernel bit for bit
+    assert torch.equal(ops.pixel_mha(qkv.to(DEV), S, T, E, heads), ops.pixel_mha(qkv.to(DEV), S, T, E, heads, p_drop=0.0, seed=5))
+
+
 def test_softmax_expert_sum_selector_backward():
     A = mod("autograd")
     g = gen(2)
@@ -475,7 +523,7 @@ def test_fusion_train_step_against_reference_fixture(mode):
     case, sd = load_golden("fusion_train.pt"), load_golden("fusion_full.pt")["sd"]
     ops.set_gemm_mode(mode)
     try:
-        tr = T.FusionTrainer(sd, DEV)
+        tr = T.FusionTrainer(sd, DEV, attn_dropout=0.0)
         lr, hr, imgs, feats = _train_inputs(case)
         tr.zero_grad()
         loss, sr = tr.forward_backward(lr, hr, imgs, feats)
@@ -530,7 +578,7 @@ def _full_step_case(mode, ofusion, otrain, train_case, T, W, FT):
     # and the HIP gradient may deviate from it by 1e-3 plus twice what fp32 CPU autograd (the reference's arithmetic) does.
     loss_o, want = oracle_grads(torch.float32)
     _, truth = oracle_grads(torch.float64)
-    tr = T.FusionTrainer(sd, DEV)
+    tr = T.FusionTrainer(sd, DEV, attn_dropout=0.0)
     loss = tr.step(*_train_inputs(case))
     assert abs(loss.item() - loss_o) < 1e-5
     got = tr.opt.views(tr.opt.grad)
@@ -567,6 +615,43 @@ def _full_step_case(mode, ofusion, otrain, train_case, T, W, FT):
     assert torch.equal(cp.fwd.wgt.cpu()[:, :128], got_p["refine.4.weight"].cpu().permute(0, 2, 3, 1).reshape(128, -1)[:, :128])
 
 
+def test_training_step_at_baseline_batch_32():
+    """BASELINE config 5's geometry: ONE step on a batch of 32 patches of 64x64 (2.1 M HR pixels: the pixel-split paths of the
+    weight-gradient kernels, the 2^21-row reductions).  The batch is 16 copies of two seeded patches, so the batch statistics of
+    the BatchNorms, the mean L1 loss and every mean gradient equal those of the 2-patch batch -- which the CPU oracle
+    (oracle/ffsr_oracle/fusion.py in train mode + torch autograd, float64) can evaluate: loss and the gradients of refine.4.weight,
+    the cross-band attention's projections and dynamic_selector.gate_net.0.weight are checked against it.  Attention dropout 0
+    (the oracle has no counter-based mask)."""
+    from ffsr_oracle import fusion as ofusion
+    from make_golden import train_case
+    T, W, FT, E = mod("train"), mod("weights"), mod("fusion_train"), mod("engine")
+    sd = {k: v for k, v in W.fusion_state_dict(seed=5).items() if v.is_floating_point() and v.numel() > 0}
+    lr, imgs, feats, hr = train_case(78, 2, 64, 64)
+    keys = ["refine.4.weight", "cross_band.band_attention.in_proj_weight", "cross_band.band_attention.out_proj.weight",
+            "cross_band.band_proj.weight", "dynamic_selector.gate_net.0.weight"]
+    s_ = {k: (v.clone().double().requires_grad_(True) if k in keys else v.clone().double()) for k, v in sd.items()}
+    sr_ = ofusion.fusion_forward(s_, lr.double(), {k: v.double() for k, v in imgs.items()}, {k: v.double() for k, v in feats.items()},
+                                 train=True)
+    l_ = F.l1_loss(sr_.clamp(0, 1), hr.double())
+    l_.backward()
+    rep = lambda t: t.repeat(16, 1, 1, 1)
+    tr = T.FusionTrainer(sd, DEV, attn_dropout=0.0)
+    tr.zero_grad()
+    loss, sr = tr.forward_backward(E.nchw_to_map(rep(lr), DEV), E.nchw_to_map(rep(hr), DEV), {k: E.nchw_to_map(rep(v), DEV) for k, v in imgs.items()},
+                                   {k: E.nchw_to_map(rep(v), DEV) for k, v in feats.items()})
+    assert tuple(sr.shape) == (32, 256, 256, 3)
+    assert abs(loss.item() - l_.item()) < 1e-5
+    got = tr.opt.views(tr.opt.grad)
+    for k in keys:
+        w = s_[k].grad
+        r = (got[k].cpu().double() - w).abs().max().item() / max(w.abs().max().item(), 1e-30)
+        print(f"B = 32 step: {k}: relative gradient error {r:.2e} (|g|max {w.abs().max().item():.1e})")
+        assert r < 3e-3, (k, r)
+    # every copy of a patch gives the same output rows
+    srn = E.map_to_nchw(sr)
+    assert (srn[0] - srn[2]).abs().max().item() < 1e-6 and (srn[1] - srn[31]).abs().max().item() < 1e-6
+
+
 def test_training_odd_size_and_gradient_accumulation():
     """ragged patch size (20x28 LR: non-power-of-2 DFT, reflect-padded DCT blocks, odd resampler ratios in the hierarchical and
     Laplacian pyramids) in the exact mode against the float64 oracle; and accumulation_steps = 2 (train.py:332-345): two
@@ -586,7 +671,7 @@ def test_training_odd_size_and_gradient_accumulation():
     truth = {k: s_[k].grad for k in names}
     ops.set_gemm_mode("f32")
     try:
-        tr = T.FusionTrainer(sd, DEV, accumulation_steps=2)
+        tr = T.FusionTrainer(sd, DEV, accumulation_steps=2, attn_dropout=0.0)
         p0 = tr.opt.param.clone()
         for i, (lr, imgs, feats, hr) in enumerate(batches):
             tr.step(*_train_inputs({"lr": lr, "hr": hr, "imgs": imgs, "feats": feats}))
@@ -614,7 +699,7 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     sd = load_golden("fusion_full.pt")["sd"]
     lr, imgs, feats, hr = train_case(91, 2, 32, 32)
     inputs = _train_inputs({"lr": lr, "hr": hr, "imgs": imgs, "feats": feats})
-    tr = T.FusionTrainer(sd, DEV, lr=1e-3)
+    tr = T.FusionTrainer(sd, DEV, lr=1e-3, attn_dropout=0.0)
     losses = [tr.step(*inputs).item() for _ in range(25)]
     print("loss: first 3", [f"{v:.5f}" for v in losses[:3]], "last 3", [f"{v:.5f}" for v in losses[-3:]])
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.9 * losses[0], losses
