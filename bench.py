@@ -230,7 +230,8 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline: also time ONE real 340x510 oracle pass (~5 min of host time)")
     ap.add_argument("--no-extras", action="store_true", help="skip the tile64 / train_step measurements after the headline one")
     ap.add_argument("--small", action="store_true", help="reduced-depth experts (plumbing check only, not a valid bench)")
-    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=None, help="GEMM arithmetic (default: the engine's default)")
+    ap.add_argument("--gemm", choices=["f32", "bf16x3", "bf16"], default=None,
+                    help="GEMM arithmetic (default: the engine's default, bf16x3; bf16 = plain bf16 operands, a precision option)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / broadcast / timing plumbing only, no engine and no GPU (CPU tests; not a bench)")
     args = ap.parse_args()
@@ -366,7 +367,8 @@ def main():
                  3: ("tok_chain_kernel", "tok_chain_kernel (token-stationary fused LayerNorm + fc1 + GELU + fc2 + residual: rows "
                      "in registers, hidden layer never leaves them, weights streamed fragment-major through LDS; 3-term "
                      "split-bf16 MFMA 16x16x32, fp32 accumulate)")}
-        mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3.0       # 3 bf16 MFMAs per algorithmic fp32 multiply-add
+        # 3 bf16 MFMAs per algorithmic fp32 multiply-add (1 in the plain-bf16 option)
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS / (1.0 if ops.gemm_mode_name() == "bf16" else 3.0)
     else:
         names = {0: ("conv_gemm_kernel", "conv_gemm_kernel (f32-input MFMA implicit GEMM)")}
         mfma_peak = MFMA_F32_PEAK_TFLOPS
@@ -408,13 +410,15 @@ def main():
         line = {"metric": f"SR output megapixels/s (x4, {w}x{h} LR -> {w * SCALE}x{h * SCALE}, full 4-expert + 7-phase fusion)",
                 "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if ops.GEMM_MODE == "f32" else "f32 (GEMM/conv products as 3-term split-bf16 MFMA, fp32 accumulate)", "data": "synthetic (seeded LR images; random-init weights of the exact architecture)",
+                "dtype": ("f32" if ops.GEMM_MODE == "f32" else
+                          "bf16 operands, f32 accumulate and storage (precision option, not the default)" if ops.gemm_mode_name() == "bf16" else
+                          "f32 (GEMM/conv products as 3-term split-bf16 MFMA, fp32 accumulate)"), "data": "synthetic (seeded LR images; random-init weights of the exact architecture)",
                 "config": {"workload": f"CompleteEnhancedFusionSR hot path: {w}x{h} LR image per step per GPU "
                                        f"(pad16 -> DRCT-L + GRL-B + NAFNet-w64 + MambaIR -> fusion), batch {args.batch}",
                            "lr_hw": [h, w], "images_per_step_per_gpu": args.batch, "parallelism": f"image-parallel x{world}",
                            "hip_graph": bool(args.graph),
                            "small_experts": bool(args.small)},
-                "gemm_mode": ops.GEMM_MODE, "roofline": roofline}
+                "gemm_mode": ops.gemm_mode_name(), "roofline": roofline}
         default_geometry = (h, w) == (H_LR, W_LR) and args.batch == 1 and not args.small and not args.graph
         if world == 1 and default_geometry and not args.no_extras:
             # ---- north_star's second geometry and BASELINE config 5, measured in the same process after the headline

@@ -47,6 +47,10 @@ static inline int ffsr_allow_dynamic_lds(const void* const* fns, int n, int byte
   return FFSR_OK;
 }
 
+// Products of the split-bf16 GEMM kernels: 3 = hi*hi + hi*lo + lo*hi (default, ~1e-5 relative per product), 1 = hi*hi only
+// (plain bf16 operands, fp32 accumulate: FFSR_GEMM_MODE=bf16, ffsr_set_gemm_terms).  Process-wide mode switch, set before use.
+extern int g_ffsr_gemm_terms;
+
 // activation codes shared by the GEMM/conv epilogue, the depthwise conv and the elementwise kernels
 enum FfsrAct : int {
   FFSR_ACT_NONE = 0,

@@ -258,7 +258,8 @@ struct ConvArgs3 {
   int M, Ktot, akrows;
 };
 
-template <int BN, bool HAS_AK>
+// TERMS 3: hi*hi + hi*lo + lo*hi; TERMS 1: plain bf16 operands (hi*hi only: no lo planes staged, one MFMA per product)
+template <int BN, bool HAS_AK, int TERMS>
 __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
   // BN = 64 / 128: 2 x 2 waves, wave tile 64 x BN/2.  BN = 32 (thin convs, N <= 32: the 3- / 16- / 32-channel heads of the
   // fusion net at HR resolution): 4 x 1 waves, wave tile 32 x 32 -- half the MFMA work of padding N to 64.
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
       if (BN < 64 && brow >= BN) break;                                          // BN = 32: half the loader threads idle
       const size_t off = (size_t)(n0 + brow + 64 * j) * p.ldw + kt * BK + bseg;   // planes are padded: always valid
       bh_reg[j] = *reinterpret_cast<const floatx4*>(p.whi + off);
-      bl_reg[j] = *reinterpret_cast<const floatx4*>(p.wlo + off);
+      if constexpr (TERMS == 3) bl_reg[j] = *reinterpret_cast<const floatx4*>(p.wlo + off);
     }
   };
   auto store_tiles = [&]() {
@@ -375,14 +376,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
       split4(a_reg[i], hi, lo);
       const int o = (rbase + 32 * i) * RS + ((((kofs >> 3) ^ ((rbase >> 2) & 3)) << 4) | ((kofs * 2) & 15));
       *reinterpret_cast<uintx2*>(Ahi + o) = hi;
-      *reinterpret_cast<uintx2*>(Alo + o) = lo;
+      if constexpr (TERMS == 3) *reinterpret_cast<uintx2*>(Alo + o) = lo;
     }
 #pragma unroll
     for (int j = 0; j < BRW; ++j) {
       if (BN < 64 && brow >= BN) break;
       const int o = (brow + 64 * j) * RS + (((tid & 3) ^ ((brow >> 2) & 3)) << 4);
       *reinterpret_cast<floatx4*>(Bhi + o) = bh_reg[j];
-      *reinterpret_cast<floatx4*>(Blo + o) = bl_reg[j];
+      if constexpr (TERMS == 3) *reinterpret_cast<floatx4*>(Blo + o) = bl_reg[j];
     }
   };
 
@@ -410,19 +411,21 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + (wrow + i * 32 + r) * RS + ko);
-        al[i] = *reinterpret_cast<const bf16x8*>(Alo + (wrow + i * 32 + r) * RS + ko);
+        if constexpr (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(Alo + (wrow + i * 32 + r) * RS + ko);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + (wcol + j * 32 + r) * RS + ko);
-        bl[j] = *reinterpret_cast<const bf16x8*>(Blo + (wcol + j * 32 + r) * RS + ko);
+        if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(Blo + (wcol + j * 32 + r) * RS + ko);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (TERMS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -587,10 +590,13 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x3_v3_kernel(ConvArgs3 p) {
 template <int BN>
 int launch_v3(const ConvArgs3& a, hipStream_t st) {
   int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
-  if (a.akscale)
-    FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, true>), dim3(tiles), dim3(256), 0, st, a);
+  if (g_ffsr_gemm_terms == 1) {
+    if (a.akscale) FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, true, 1>), dim3(tiles), dim3(256), 0, st, a);
+    else FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, false, 1>), dim3(tiles), dim3(256), 0, st, a);
+  } else if (a.akscale)
+    FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, true, 3>), dim3(tiles), dim3(256), 0, st, a);
   else
-    FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, false>), dim3(tiles), dim3(256), 0, st, a);
+    FFSR_LAUNCH((conv_gemm_bf16x3_v3_kernel<BN, false, 3>), dim3(tiles), dim3(256), 0, st, a);
   return ffsr_launch_status();
 }
 
@@ -654,6 +660,15 @@ extern "C" int ffsr_conv2d_f32(const float* in, const float* wgt, const float* b
 }
 
 // Split-bf16 convolution with pre-split weights: see include/ffsr.h.
+int g_ffsr_gemm_terms = 3;
+
+// See include/ffsr.h.
+extern "C" int ffsr_set_gemm_terms(int terms) {
+  FFSR_CHECK(terms == 1 || terms == 3);
+  g_ffsr_gemm_terms = terms;
+  return FFSR_OK;
+}
+
 extern "C" int ffsr_conv2d_bf16x3(const float* in, const void* wgt_hi, const void* wgt_lo, int ldw, int n_rows_padded,
                                   const float* zeros, const float* bias, float* out, const float* res, const float* cvec,
                                   const float* rvec, const float* akscale, int B, int H, int W, int Cin, int ldi, int N,

@@ -234,7 +234,9 @@ __device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&a
 // GELU: exact-erf GELU epilogue; otherwise the epilogue activation is v > 0 ? v : v * slope (none: slope 1, ReLU: 0).
 // SCHED 1: the LDS-DMA pieces of the next K step are issued one at a time between the MFMA triples of the current step
 // (a burst of 10 pieces right after the barrier costs 100-185 issue cycles each with the matrix pipe idle).
-template <int BM, int BN, int STAGES, bool GELU, int SCHED>
+// TERMS 3: hi*hi + hi*lo + lo*hi.  TERMS 1 (plain-bf16 mode): only the hi planes are staged (half the LDS-DMA pieces, half the
+// operand bytes) and each product is one MFMA.
+template <int BM, int BN, int STAGES, bool GELU, int SCHED, int TERMS>
 __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
   FFSR_STAMP(0);
   constexpr int NW = BM / 32;                                // waves: (BM / 64) x 2
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
   constexpr int STAGE = 2 * (PLANE_A + PLANE_B);
   constexpr int NB = (BN / 16 + NW - 1) / NW;                // B pieces (LDS-DMA instructions) per wave and plane
   constexpr bool B_EVEN = (BN / 16) % NW == 0;               // every wave owns NB pieces (else the last round is partial)
-  constexpr int LOADS = 2 * (2 + NB);                        // LDS-DMA instructions per wave and K step (full waves)
+  constexpr int PLN = TERMS == 3 ? 2 : 1;                    // planes staged per operand
+  constexpr int LOADS = PLN * (2 + NB);                      // LDS-DMA instructions per wave and K step (full waves)
   static_assert(STAGES == 2 || B_EVEN, "counted vmcnt needs the same number of loads in every wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // STAGES * STAGE bytes (>= 4 * 9216 for the epilogue)
 
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
   const int cpt = p.Cp >> 5;
   unsigned i_koff = 0;   // byte offset of K step in a weight row
   // one LDS-DMA piece of K step (i_tap, i_cc): idx 0..3 = A (row block idx>>1, plane idx&1), 4.. = B (piece (idx-4)>>1, plane)
-  auto issue_piece = [&](int stage, int idx, bool valid) {
+  auto issue_piece = [&](int stage, int li, bool valid) {
+    const int idx = TERMS == 3 ? li : 2 * li;      // hi-only staging: the even (hi-plane) pieces of the 3-term numbering
     unsigned char* base = smem + stage * STAGE;
     if (idx < 4) {
       const int i = idx >> 1;
@@ -376,17 +380,19 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8*>(A + i * 2048 + fo);
-        al[i] = *reinterpret_cast<const bf16x8*>(A + PLANE_A + i * 2048 + fo);
+        if constexpr (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(A + PLANE_A + i * 2048 + fo);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const bf16x8*>(Bt + j * 2048 + fo);
-        bl[j] = *reinterpret_cast<const bf16x8*>(Bt + PLANE_B + j * 2048 + fo);
+        if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(Bt + PLANE_B + j * 2048 + fo);
       }
       static_for<0, TM * TN>([&](auto tc) {
         constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        if constexpr (TERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         if constexpr (SCHED == 1) {
           constexpr int GROUPS = 2 * TM * TN;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
 #pragma unroll
           for (int idx = 0; idx < LOADS; ++idx)
             if (idx * GROUPS / LOADS == g) issue_piece(is, idx, more);
-          __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);      // 3 MFMA, then this triple's pieces
+          __builtin_amdgcn_sched_group_barrier(0x8, TERMS, 0);  // the product's MFMAs, then its pieces
           constexpr int c0 = pieces_in_group(t, GROUPS, LOADS), c1 = pieces_in_group(TM * TN + t, GROUPS, LOADS);
           if (ks == 0) { if constexpr (c0 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c0, 0); }
           else { if constexpr (c1 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c1, 0); }
@@ -414,17 +420,22 @@ __global__ __launch_bounds__(BM * 2) void conv_gemm_planes_kernel(PlaneArgs p) {
   FFSR_STAMP(5);                  // epilogue done (stores issued)
 }
 
-template <int BM, int BN, int STAGES, bool GELU, int SCHED>
-int launch_planes3(const PlaneArgs& a, hipStream_t st) {
+template <int BM, int BN, int STAGES, bool GELU, int SCHED, int TERMS>
+int launch_planes4(const PlaneArgs& a, hipStream_t st) {
   constexpr int STAGE = 2 * (BM + BN) * 64;
   static_assert(STAGES * STAGE >= (BM / 32) * 32 * 36 * 4, "epilogue scratch");
   static_assert(STAGES * STAGE <= 160 * 1024, "LDS");
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static unsigned long long attr_set = 0;
-  const void* fn = reinterpret_cast<const void*>(&conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>);
+  const void* fn = reinterpret_cast<const void*>(&conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED, TERMS>);
   if (ffsr_allow_dynamic_lds(&fn, 1, STAGES * STAGE, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
-  FFSR_LAUNCH((conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED>), dim3(tiles), dim3(BM * 2), STAGES * STAGE, st, a);
+  FFSR_LAUNCH((conv_gemm_planes_kernel<BM, BN, STAGES, GELU, SCHED, TERMS>), dim3(tiles), dim3(BM * 2), STAGES * STAGE, st, a);
   return ffsr_launch_status();
+}
+
+template <int BM, int BN, int STAGES, bool GELU, int SCHED>
+int launch_planes3(const PlaneArgs& a, hipStream_t st) {
+  return g_ffsr_gemm_terms == 1 ? launch_planes4<BM, BN, STAGES, GELU, SCHED, 1>(a, st) : launch_planes4<BM, BN, STAGES, GELU, SCHED, 3>(a, st);
 }
 
 #ifdef FFSR_PLANES_PROBE
@@ -452,7 +463,8 @@ int launch_planes(PlaneArgs& a, hipStream_t st) {
 // down by kx: one 130-row strip (144 staged) per (ky, 32-channel chunk) serves kx = 0, 1, 2 through fragment reads at row
 // offsets 0 / 1 / 2 -- 9 pieces per plane instead of 24.  What a shifted read picks up across an image border (the
 // neighbouring pixel of the previous / next image row) is zeroed in the fragment registers from the per-row tap mask.
-template <int BN, bool GELU, int SCHED>
+// TERMS 1 (plain-bf16 mode): one MFMA per product on the hi planes (both planes are still staged here).
+template <int BN, bool GELU, int SCHED, int TERMS>
 __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64, NW = 4;
   constexpr int SROWS = 144;                                  // 130 used, staged in 16-row pieces
@@ -606,8 +618,10 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
         }
         static_for<0, TM * TN>([&](auto tc) {
           constexpr int tt = decltype(tc)::value, i = tt / TN, j = tt % TN;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (TERMS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           if constexpr (SCHED == 1) {
             // one LDS-DMA piece after each MFMA triple instead of a burst behind the barrier
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
 #pragma unroll
             for (int idx = 0; idx < LOADS; ++idx)
               if (idx * GROUPS / LOADS == g) issue_piece(idx);
-            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, TERMS, 0);
             constexpr int c0 = pieces_in_group(tt, GROUPS, LOADS), c1 = pieces_in_group(TM * TN + tt, GROUPS, LOADS);
             if (ks == 0) { if constexpr (c0 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c0, 0); }
             else { if constexpr (c1 > 0) __builtin_amdgcn_sched_group_barrier(0x20, c1, 0); }
@@ -632,16 +646,20 @@ __global__ __launch_bounds__(256) void conv3_strip_planes_kernel(PlaneArgs p) {
   planes_epilogue<TM, TN, GELU>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), m0, n0, wrow, wcol, lane);
 }
 
-template <int BN, bool GELU, int SCHED>
-int launch_strip3(const PlaneArgs& a, hipStream_t st) {
+template <int BN, bool GELU, int SCHED, int TERMS>
+int launch_strip4(const PlaneArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * (2 * 144 * 64) + 2 * (2 * BN * 64);
   static_assert(LDS >= 4 * 32 * 36 * 4, "epilogue scratch");
   const int tiles = ((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
   static unsigned long long attr_set = 0;
-  const void* fn = reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU, SCHED>);
+  const void* fn = reinterpret_cast<const void*>(&conv3_strip_planes_kernel<BN, GELU, SCHED, TERMS>);
   if (ffsr_allow_dynamic_lds(&fn, 1, LDS, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
-  FFSR_LAUNCH((conv3_strip_planes_kernel<BN, GELU, SCHED>), dim3(tiles), dim3(256), LDS, st, a);
+  FFSR_LAUNCH((conv3_strip_planes_kernel<BN, GELU, SCHED, TERMS>), dim3(tiles), dim3(256), LDS, st, a);
   return ffsr_launch_status();
+}
+template <int BN, bool GELU, int SCHED>
+int launch_strip3(const PlaneArgs& a, hipStream_t st) {
+  return g_ffsr_gemm_terms == 1 ? launch_strip4<BN, GELU, SCHED, 1>(a, st) : launch_strip4<BN, GELU, SCHED, 3>(a, st);
 }
 // Measured (tools/strip_bench.py): with the 64-column tile (6 MFMAs per K half) the burst of 4 pieces behind the barrier is
 // faster than one piece per MFMA triple (N 45: 132 vs 147 us, N 60: 156 vs 161, 64 -> 64 at HR/2: 187 vs 201); with the

@@ -165,7 +165,8 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
 // MODE 2: no second GEMM: out = act(W1 pre(x) + b1) * cvec * cscale, 32 output features per step, stored per step (the rows of
 //         W1 are packed in the lane-column order, so a lane stores 8 consecutive columns per step); NT2 is unused (2)
 // RX: the residual is the input row itself (accumulators start from it; requires K == N, NT2 == 2 KS1)
-template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH>
+// TERMS 1 (plain-bf16 mode): one MFMA per product on the hi halves of the fragments.
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int TERMS>
 __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   constexpr int G = MODE == 1 ? 4 : 2;
   constexpr int F1 = G * KS1 * 2;                  // 1 KB pieces of a W1 fill
@@ -270,8 +271,10 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
           for (int g = 0; g < 2; ++g) {
             const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 0) * 1024);
             const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 1) * 1024);
-            hx[g] = mfma16(wh, a_lo[s], hx[g]);
-            hx[g] = mfma16(wl, a_hi[s], hx[g]);
+            if constexpr (TERMS == 3) {
+              hx[g] = mfma16(wh, a_lo[s], hx[g]);
+              hx[g] = mfma16(wl, a_hi[s], hx[g]);
+            }
             hx[g] = mfma16(wh, a_hi[s], hx[g]);
           }
         }
@@ -331,8 +334,10 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
           const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 0) * 1024);
           const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S1 + ((g * KS1 + s) * 2 + 1) * 1024);
 #endif
-          hx[g] = mfma16(wh, a_lo[s], hx[g]);
-          hx[g] = mfma16(wl, a_hi[s], hx[g]);
+          if constexpr (TERMS == 3) {
+            hx[g] = mfma16(wh, a_lo[s], hx[g]);
+            hx[g] = mfma16(wl, a_hi[s], hx[g]);
+          }
           hx[g] = mfma16(wh, a_hi[s], hx[g]);
         }
       }
@@ -373,8 +378,10 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
         const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S2 + (n * 2 + 0) * 1024);
         const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S2 + (n * 2 + 1) * 1024);
 #endif
-        acc[n] = mfma16(wh, h_lo, acc[n]);
-        acc[n] = mfma16(wl, h_hi, acc[n]);
+        if constexpr (TERMS == 3) {
+          acc[n] = mfma16(wh, h_lo, acc[n]);
+          acc[n] = mfma16(wl, h_hi, acc[n]);
+        }
         acc[n] = mfma16(wh, h_hi, acc[n]);
       }
     }
@@ -384,15 +391,15 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   wait_vm<0>();     // the dummy pieces of the last fills
 }
 
-template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH>
-int launch_tok(const TokArgs& a, hipStream_t st) {
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int TERMS>
+int launch_tok4(const TokArgs& a, hipStream_t st) {
   constexpr int G = MODE == 1 ? 4 : 2;
   constexpr int F1 = G * KS1 * 2, F2 = MODE == 2 ? 0 : NT2 * 2, FMAX = F1 > F2 ? F1 : F2;
   const int lds = D * FMAX * 1024 + WAVES * 1024 + a.steps * G * 16 * 4;
   if (lds > 160 * 1024) return FFSR_EINVAL;
   static unsigned long long attr_set = 0;
   static int num_cu = 0;
-  const void* fn = reinterpret_cast<const void*>(&tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH>);
+  const void* fn = reinterpret_cast<const void*>(&tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH, TERMS>);
   if (ffsr_allow_dynamic_lds(&fn, 1, 160 * 1024, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
   if (!num_cu) {
     int dev = 0;
@@ -404,8 +411,14 @@ int launch_tok(const TokArgs& a, hipStream_t st) {
   const int ntile = (a.M + per - 1) / per;
   const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;     // small rings (NAFNet widths): two workgroups share a CU
   const int grid = ntile < num_cu * wg_per_cu ? ntile : num_cu * wg_per_cu;
-  FFSR_LAUNCH((tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+  FFSR_LAUNCH((tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH, TERMS>), dim3(grid), dim3(WAVES * 64), lds, st, a);
   return ffsr_launch_status();
+}
+
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH>
+int launch_tok(const TokArgs& a, hipStream_t st) {
+  return g_ffsr_gemm_terms == 1 ? launch_tok4<KS1, NT2, WAVES, D, MODE, RX, PFETCH, 1>(a, st)
+                                : launch_tok4<KS1, NT2, WAVES, D, MODE, RX, PFETCH, 3>(a, st);
 }
 
 template <int KS1, int NT2, int MODE, bool RX>

@@ -52,6 +52,8 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the .so does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        if os.environ.get("FFSR_GEMM_MODE") == "bf16":      # plain-bf16 products (see ops.set_gemm_mode)
+            handle.ffsr_set_gemm_terms(1)
         _lib = handle
     return _lib
 

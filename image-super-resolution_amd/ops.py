@@ -24,7 +24,8 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SILU = range(6)
 #            Default: full-depth parity vs the oracle is 1e-5 max-abs (PSNR 116 dB), 100x inside north_star's 1e-3
 #            (tests/test_gpu_models.py::test_full_depth_experts_and_fusion_vs_oracle_64x64).  FFSR_GEMM_MODE=f32 selects
 #            the exact kernel.
-GEMM_MODE = os.environ.get("FFSR_GEMM_MODE", "bf16x3")
+_ENV_MODE = os.environ.get("FFSR_GEMM_MODE", "bf16x3")
+GEMM_MODE = "bf16x3" if _ENV_MODE == "bf16" else _ENV_MODE      # "bf16" = the bf16x3 kernels with one product term (hip.lib() sets it)
 
 
 # Precision-budget experiment: FFSR_WEIGHT_LO=0 packs every weight with a ZERO lo plane, i.e. the split-bf16
@@ -41,11 +42,22 @@ def set_weight_lo(on: bool):
 BN128_MIN_N = 1 << 30   # the 128-column tile (2 waves/SIMD) measured slower on every shape: keep BN = 64
 
 
+GEMM_TERMS = 1 if _ENV_MODE == "bf16" else 3
+
+
 def set_gemm_mode(mode: str):
-    """"bf16x3": GEMMs, convs and DRCT's window attention on the split-bf16 MFMA; "f32": the exact kernels everywhere."""
-    global GEMM_MODE
-    assert mode in ("f32", "bf16x3")
-    GEMM_MODE = mode
+    """"bf16x3": GEMMs, convs and DRCT's window attention on the split-bf16 MFMA; "f32": the exact kernels everywhere;
+    "bf16": the bf16x3 kernels with ONE product term (plain bf16 operands, fp32 accumulate: BASELINE config 2's named precision;
+    ~2e-2 max-abs on NAFNet alone -- a precision option, never the default)."""
+    global GEMM_MODE, GEMM_TERMS
+    assert mode in ("f32", "bf16x3", "bf16")
+    GEMM_TERMS = 1 if mode == "bf16" else 3
+    GEMM_MODE = "bf16x3" if mode == "bf16" else mode       # same kernels, same dispatch; only the product terms differ
+    hip.call("ffsr_set_gemm_terms", GEMM_TERMS)
+
+
+def gemm_mode_name() -> str:
+    return "bf16" if (GEMM_MODE == "bf16x3" and GEMM_TERMS == 1) else GEMM_MODE
 
 
 # bench.py sets this to a list to time every conv/GEMM launch with events on the launch stream:

@@ -41,6 +41,13 @@ int ffsr_conv2d_f32(const float* in, const float* wgt, const float* bias, float*
                     int N, int ldo, int ldr, int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
                     float cscale, float rscale, int shuffle, int akrows, int tile_hint, void* stream);
 
+/* Arithmetic of the split-bf16 kernels (ffsr_conv2d_bf16x3, ffsr_conv2d_planes, ffsr_tok_*): terms = 3 (default) evaluates each
+ * fp32 product as hi*hi + hi*lo + lo*hi on the bf16 MFMA; terms = 1 is PLAIN bf16 -- operands rounded to bf16, one MFMA per
+ * product, fp32 accumulate (the reference's GPU route runs under torch autocast, models/team29_FreqFusionSR/io.py:263; BASELINE
+ * config 2 is quoted in bf16).  ~2e-2 max-abs on NAFNet alone: a precision option (FFSR_GEMM_MODE=bf16), never the default.
+ * Process-wide; set it before the first launch of a run. */
+int ffsr_set_gemm_terms(int terms);
+
 /* Same operator with the products evaluated as 3-term split-bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate;
  * ~1e-5 relative per product).  wgt_hi / wgt_lo: bf16 planes [n_rows_padded, ldw] of the weight matrix, pre-split at
  * pack time (hi = bf16(w), lo = bf16(w - hi)) and zero padded to n_rows_padded % bn == 0 rows and ldw % 32 == 0

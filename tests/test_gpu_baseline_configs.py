@@ -34,19 +34,29 @@ def _config2_case():
     return _CFG2["case"]
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", ["bf16x3", "f32", "bf16"])
 def test_config2_nafnet_alone_256x256(mode):
+    """bf16x3 (default) and f32 meet north_star's 1e-3 max-abs.  bf16 = BASELINE config 2's named precision (plain bf16 operands,
+    one MFMA per product, fp32 accumulate; the reference's GPU route runs under autocast): its max-abs is ~2e-2 (measured:
+    profiles/r02_precision_budget.txt 2.3e-2 at 64x64, printed below), so it is a precision OPTION -- the bar here is image
+    fidelity: PSNR(hip, oracle) measured 50.4 dB with these random weights (bar: >= 45 dB), i.e. the arithmetic noise is ~20 dB
+    below the ~30 dB error of super-resolution itself, but NOT "identical to 3 s.f." -- which is why it is not the default."""
     ops = mod("ops")
     sd, lr, want_sr, want_feat = _config2_case()
     ops.set_gemm_mode(mode)
     try:
+        assert ops.gemm_mode_name() == mode
         sr, feat = run_expert(mod("nafnet").NAFNetSR(sd, DEV), lr)
     finally:
         ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
     assert tuple(sr.shape) == (1, 3, 1024, 1024) and tuple(feat.shape) == tuple(want_feat.shape)
     e_sr, e_feat = err(sr, want_sr), err(feat, want_feat)
-    print(f"[{mode}] NAFNet 256x256: sr max abs err {e_sr:.2e}, feature max abs err {e_feat:.2e}")
-    assert e_sr < TOL and e_feat < TOL * max(1.0, want_feat.abs().max().item()), (mode, e_sr, e_feat)
+    psnr = -10.0 * torch.log10(((sr - want_sr) ** 2).mean()).item()
+    print(f"[{mode}] NAFNet 256x256: sr max abs err {e_sr:.2e}, feature max abs err {e_feat:.2e}, PSNR(hip, oracle) {psnr:.1f} dB")
+    if mode == "bf16":
+        assert psnr >= 45.0 and e_sr < 0.1, (psnr, e_sr)     # measured on MI355X: 50.4 dB, max-abs 1.7e-2 (8-bit significands)
+    else:
+        assert e_sr < TOL and e_feat < TOL * max(1.0, want_feat.abs().max().item()), (mode, e_sr, e_feat)
 
 
 def test_config3_full_path_batch16_64x64():

@@ -1,5 +1,6 @@
-"""BASELINE config 2: NAFNet-width64 + pixel-shuffle x4 alone on a 256x256 LR image (1024x1024 out), both arithmetic modes:
-time per image (events, 20 reps after 3 warm-ups), output MP/s, and max-abs error vs the CPU oracle.
+"""BASELINE config 2: NAFNet-width64 + pixel-shuffle x4 alone on a 256x256 LR image (1024x1024 out), the three arithmetic
+modes (bf16x3 = default, f32 = exact, bf16 = plain bf16 operands: the precision BASELINE names): time per image (events, 20 reps
+after 3 warm-ups), output MP/s, max-abs error and PSNR vs the CPU oracle.
 usage (GPU box): python tools/config2_bench.py"""
 import importlib
 import os
@@ -23,7 +24,7 @@ def main():
     lr = lr_image(21, 1, 256, 256)
     with torch.no_grad():
         want, _ = onaf.nafnet_sr(sd, lr)
-    for mode in ("bf16x3", "f32"):
+    for mode in ("bf16x3", "f32", "bf16"):
         ops.set_gemm_mode(mode)
         net = N.NAFNetSR(sd, "cuda")
         x = E.nchw_to_map(lr, "cuda")
@@ -37,9 +38,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
-        err = (E.map_to_nchw(sr) - want).abs().max().item()
+        got = E.map_to_nchw(sr)
+        err = (got - want).abs().max().item()
+        psnr = -10.0 * torch.log10(((got - want) ** 2).mean()).item()
         print(f"config 2 [{mode}]: {ms:.2f} ms per 256x256 LR image = {1.048576 / ms * 1e3:.1f} output-MP/s "
-              f"({2.02 / ms * 1e3:.0f} TFLOP/s algorithmic), max|hip - oracle| = {err:.2e}", flush=True)
+              f"({2.02 / ms * 1e3:.0f} TFLOP/s algorithmic), max|hip - oracle| = {err:.2e}, PSNR(hip, oracle) = {psnr:.1f} dB", flush=True)
+    ops.set_gemm_mode(os.environ.get("FFSR_GEMM_MODE", "bf16x3"))
 
 
 if __name__ == "__main__":
