@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4;
-  const int nfill = MODE == 2 ? p.steps : 2 * p.steps;
+  const int nfill = (MODE == 2 ? p.steps : 2 * p.steps) + p.tsteps;     // + the fills of the optional tail GEMM
   const int ntile = (p.M + 16 * WAVES - 1) / (16 * WAVES);
   const int my_tiles = (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles blockIdx.x, + gridDim.x, ...
   const int total_fills = my_tiles * nfill;
@@ -194,9 +194,13 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
 #if !(FFSR_TOK_ABL & 8)
     const bool live = fg < total_fills;
     const int f = fg % nfill;
-    const bool second = MODE != 2 && (f & 1);
-    const int npiece = second ? F2 : F1;
-    const unsigned char* src0 = MODE == 2 ? p.w1 + (size_t)f * (F1 * 1024)
+    const int nmain = nfill - p.tsteps;
+    const bool tail = f >= nmain;                    // (tail fills have the W1 shape of 2 tiles: F3 = 2 KS1 2 pieces)
+    const bool second = MODE != 2 && !tail && (f & 1);
+    constexpr int F3 = 2 * KS1 * 2;
+    const int npiece = tail ? F3 : (second ? F2 : F1);
+    const unsigned char* src0 = tail ? p.w3 + (size_t)(f - nmain) * (F3 * 1024)
+                              : MODE == 2 ? p.w1 + (size_t)f * (F1 * 1024)
                               : (second ? p.w2 + (size_t)(f >> 1) * (F2 * 1024) : p.w1 + (size_t)(f >> 1) * (F1 * 1024));
     unsigned char* slot = smem + (fg % D) * SLOT;
 #pragma unroll
@@ -216,6 +220,8 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   // hidden bias -> LDS (read per step with one ds_read_b128 per tile; a global load inside the loop would make the compiler
   // drain the LDS-DMA ring with vmcnt(0))
   for (int i = threadIdx.x; i < p.steps * G * 16; i += WAVES * 64) b1s[i] = p.b1[i];
+  float* const b3s = b1s + p.steps * G * 16;
+  for (int i = threadIdx.x; i < p.tsteps * 32; i += WAVES * 64) b3s[i] = p.b3[i];
 
   auto tile_row = [&](int tile, long long& tok, bool& ok) -> size_t {
     tok = ((long long)tile * WAVES + wave) * 16 + (lane & 15);
@@ -386,6 +392,58 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       }
     }
     tok_epilogue<NT2>(p, acc, tok, tok_ok, row, q);
+    if constexpr (MODE != 2 && NT2 == 2 * KS1) {
+      if (p.tsteps) {
+        // ---- tail: the chain's output row (acc, already in operand order: tile pair (2 s, 2 s + 1) = k step s) feeds one more GEMM
+        bf16x8 t_hi[KS1], t_lo[KS1];
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+          unsigned hh[4], ll[4];
+          split4(acc[2 * s], hh[0], hh[1], ll[0], ll[1]);
+          split4(acc[2 * s + 1], hh[2], hh[3], ll[2], ll[3]);
+          t_hi[s] = __builtin_bit_cast(bf16x8, uintx4{hh[0], hh[1], hh[2], hh[3]});
+          t_lo[s] = __builtin_bit_cast(bf16x8, uintx4{ll[0], ll[1], ll[2], ll[3]});
+        }
+        const int fmain = fbase + nfill - p.tsteps;
+        for (int ts = 0; ts < p.tsteps; ++ts) {
+#if !(FFSR_TOK_ABL & 4)
+          wait_vm<(D - 2) * PPW>();
+          __builtin_amdgcn_s_barrier();
+#endif
+          issue_fill(fmain + ts + D - 1);
+          const unsigned char* S3 = smem + ((fmain + ts) % D) * SLOT + lane * 16;
+          floatx4 hx[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int s = 0; s < KS1; ++s) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S3 + ((g * KS1 + s) * 2 + 0) * 1024);
+              const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S3 + ((g * KS1 + s) * 2 + 1) * 1024);
+              if constexpr (TERMS == 3) {
+                hx[g] = mfma16(wh, t_lo[s], hx[g]);
+                hx[g] = mfma16(wl, t_hi[s], hx[g]);
+              }
+              hx[g] = mfma16(wh, t_hi[s], hx[g]);
+            }
+          }
+          const float* bs = b3s + ts * 32 + 4 * q;
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int col = 32 * ts + 8 * q + 4 * g;
+            floatx4 v = hx[g] + *reinterpret_cast<const floatx4*>(bs + 16 * g);
+            if (p.act3 != FFSR_ACT_NONE) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * p.slope3;
+            }
+            v *= p.cscale3;
+            if (tok_ok && col < p.N3) {
+              if (p.res3) v += *reinterpret_cast<const floatx4*>(p.res3 + row * p.ldr3 + col) * p.rscale3;
+              *reinterpret_cast<floatx4*>(p.out3 + (size_t)tok * p.ldo3 + col) = v;
+            }
+          }
+        }
+      }
+    }
     if constexpr (!PFETCH) fetch_next();
   }
   wait_vm<0>();     // the dummy pieces of the last fills
@@ -395,7 +453,7 @@ template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, in
 int launch_tok4(const TokArgs& a, hipStream_t st) {
   constexpr int G = MODE == 1 ? 4 : 2;
   constexpr int F1 = G * KS1 * 2, F2 = MODE == 2 ? 0 : NT2 * 2, FMAX = F1 > F2 ? F1 : F2;
-  const int lds = D * FMAX * 1024 + WAVES * 1024 + a.steps * G * 16 * 4;
+  const int lds = D * FMAX * 1024 + WAVES * 1024 + a.steps * G * 16 * 4 + a.tsteps * 32 * 4;
   if (lds > 160 * 1024) return FFSR_EINVAL;
   static unsigned long long attr_set = 0;
   static int num_cu = 0;
@@ -438,13 +496,15 @@ int launch_tok_w(const TokArgs& a, int waves, hipStream_t st) {
 
 }  // namespace
 
-// See include/ffsr.h for the contract.
-extern "C" int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
-                                  const float* cvec, const float* res, int ldr, const float* rvec, const float* g2,
-                                  const float* be2, const float* res2, int ldr2, float* out, int ldo, void* out_hi,
-                                  void* out_lo, int ldp, long long M, int K, int N, int steps, int mode, int pre_ln,
-                                  float eps1, float eps2, float cscale, float rscale, int waves, void* stream) {
-  FFSR_CHECK(x && w1 && b1 && w2 && (out || (out_hi && out_lo)) && M > 0 && M < (1ll << 31));
+namespace {
+int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                     const float* cvec, const float* res, int ldr, const float* rvec, const float* g2, const float* be2,
+                     const float* res2, int ldr2, float* out, int ldo, void* out_hi, void* out_lo, int ldp, long long M, int K,
+                     int N, int steps, int mode, int pre_ln, float eps1, float eps2, float cscale, float rscale, int waves,
+                     const void* w3, const float* b3, const float* res3, int ldr3, float* out3, int ldo3, int N3, int act3,
+                     float slope3, float cscale3, float rscale3, void* stream) {
+  const bool tail = w3 != nullptr;
+  FFSR_CHECK(x && w1 && b1 && w2 && (out || (out_hi && out_lo) || tail) && M > 0 && M < (1ll << 31));
   FFSR_CHECK(K > 0 && N > 0 && steps > 0 && (K & 3) == 0 && (N & 3) == 0 && ldx >= K && (ldx & 3) == 0);
   FFSR_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)b1 & 3) == 0);
   FFSR_CHECK(!out || (ldo >= N && (ldo & 3) == 0 && ((uintptr_t)out & 15) == 0));
@@ -455,11 +515,21 @@ extern "C" int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const
              (!g2 || (((uintptr_t)g2 & 15) == 0 && ((uintptr_t)be2 & 15) == 0)));
   FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= N && ldp < N + 32 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0));
   FFSR_CHECK(mode == 0 || mode == 1);
-  TokArgs a;
+  if (tail) {
+    FFSR_CHECK(b3 && out3 && N3 > 0 && (N3 & 3) == 0 && ldo3 >= N3 && (ldo3 & 3) == 0 && ((uintptr_t)out3 & 15) == 0 && ((uintptr_t)w3 & 15) == 0);
+    FFSR_CHECK(!res3 || (ldr3 >= N3 && (ldr3 & 3) == 0 && ((uintptr_t)res3 & 15) == 0));
+    FFSR_CHECK(act3 == FFSR_ACT_NONE || act3 == FFSR_ACT_RELU || act3 == FFSR_ACT_LRELU);
+    FFSR_CHECK((K + 31) / 32 == (N + 31) / 32);       // the tail contracts over the chain's N outputs with the K-step count of its input
+  }
+  TokArgs a = {};
   a.x = x; a.w1 = (const unsigned char*)w1; a.b1 = b1; a.w2 = (const unsigned char*)w2; a.b2 = b2; a.cvec = cvec; a.res = res;
   a.rvec = rvec; a.g2 = g2; a.be2 = be2; a.res2 = res2; a.out = out; a.o_hi = (unsigned short*)out_hi; a.o_lo = (unsigned short*)out_lo;
   a.ldx = ldx; a.ldr = ldr; a.ldr2 = ldr2; a.ldo = ldo; a.ldp = ldp; a.M = (int)M; a.K = K; a.N = N; a.steps = steps;
   a.pre_ln = pre_ln; a.eps1 = eps1; a.eps2 = eps2; a.cscale = cscale; a.rscale = rscale; a.act = 0; a.slope = 0.f;
+  if (tail) {
+    a.w3 = (const unsigned char*)w3; a.b3 = b3; a.res3 = res3; a.out3 = out3; a.ldr3 = ldr3; a.ldo3 = ldo3; a.N3 = N3;
+    a.tsteps = (N3 + 31) / 32; a.act3 = act3; a.slope3 = act3 == FFSR_ACT_RELU ? 0.f : slope3; a.cscale3 = cscale3; a.rscale3 = rscale3;
+  }
   const int ks1 = (K + 31) / 32, nt2 = (N + 31) / 32 * 2;      // an even number of 16-column tiles
   // x + f(x): the residual is the row the wave holds anyway (no second read), when nothing scales either side
   a.res_is_x = (res == x && ldr == ldx && K == N && !cvec && !rvec && cscale == 1.0f && rscale == 1.0f && nt2 == 2 * ks1) ? 1 : 0;
@@ -479,6 +549,29 @@ extern "C" int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const
   FFSR_TOK_CASE(4, 8, 1);
 #undef FFSR_TOK_CASE
   return FFSR_EINVAL;
+}
+}  // namespace
+
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                                  const float* cvec, const float* res, int ldr, const float* rvec, const float* g2,
+                                  const float* be2, const float* res2, int ldr2, float* out, int ldo, void* out_hi,
+                                  void* out_lo, int ldp, long long M, int K, int N, int steps, int mode, int pre_ln,
+                                  float eps1, float eps2, float cscale, float rscale, int waves, void* stream) {
+  return tok_chain_common(x, ldx, w1, b1, w2, b2, cvec, res, ldr, rvec, g2, be2, res2, ldr2, out, ldo, out_hi, out_lo, ldp, M, K, N,
+                          steps, mode, pre_ln, eps1, eps2, cscale, rscale, waves, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0.f,
+                          1.f, 1.f, stream);
+}
+
+extern "C" int ffsr_tok_chain_tail_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                                       const float* res, int ldr, float* out, int ldo, long long M, int K, int N, int steps,
+                                       int mode, int pre_ln, float eps1, const void* w3, const float* b3, const float* res3,
+                                       int ldr3, float* out3, int ldo3, int N3, int act3, float slope3, float cscale3,
+                                       float rscale3, int waves, void* stream) {
+  FFSR_CHECK(w3);
+  return tok_chain_common(x, ldx, w1, b1, w2, b2, nullptr, res, ldr, nullptr, nullptr, nullptr, nullptr, 0, out, ldo, nullptr, nullptr,
+                          0, M, K, N, steps, mode, pre_ln, eps1, 1e-5f, 1.f, 1.f, waves, w3, b3, res3, ldr3, out3, ldo3, N3, act3,
+                          slope3, cscale3, rscale3, stream);
 }
 
 // See include/ffsr.h for the contract.

@@ -32,6 +32,14 @@ struct TokArgs {
   float eps1, eps2, cscale, rscale;
   int act;                   // MODE 2: epilogue activation (FfsrAct)
   float slope;
+  // optional TAIL of the chain (MODE 0 / 1): a third linear layer applied to the chain's output row while it is still in
+  // registers -- out3 = act3(W3 y + b3) * cscale3 + res3 * rscale3 (DRCT's dense-block "adjust" 1x1 convolutions)
+  const unsigned char* w3;   // fragment-major [tsteps][2][KS1][2][64][8] (pack_tok_gemm layout: rows in lane-column order) or null
+  const float* b3;           // [tsteps * 32]
+  const float* res3;         // [M, ldr3] or null
+  float* out3;               // [M, ldo3]
+  int ldr3, ldo3, N3, tsteps, act3;
+  float slope3, cscale3, rscale3;
 };
 
 template <int N>

@@ -11,6 +11,10 @@ from . import ops
 from .common import SRTail, dev, to_map, tokens
 from .ops import ACT_GELU, ACT_LRELU
 
+import os
+
+TAIL_FUSED = os.environ.get("FFSR_TOK_TAIL", "1") != "0"   # FFSR_TOK_TAIL=0: adjust convolutions as their own launches (A/B runs)
+
 
 class _Swin:
     def __init__(self, sd, p, device, dim, heads, ws, shift):
@@ -32,8 +36,9 @@ class _Swin:
                                       sd[p + "mlp.fc2.bias"], device, mode=0, ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"])) \
             if ops.tok_chain_ok(dim, dim, 0) else None
 
-    def __call__(self, x, B, H, W):
-        """x [P, dim] (row stride may be wider) -> [P, dim]"""
+    def __call__(self, x, B, H, W, tail=None):
+        """x [P, dim] (row stride may be wider) -> [P, dim]; tail (see ops.tok_chain): the dense block's adjust convolution rides
+        in the MLP kernel and the block's own output is not stored -> returns None"""
         pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"   # LN / fc1 results go to the GEMMs as bf16 hi/lo planes
         if self.qkv_t is not None and ops.tok_enabled():
             qkv = ops.tok_gemm(x, self.qkv_t)
@@ -43,6 +48,9 @@ class _Swin:
         a = ops.window_attn(qkv, self.bias, B, H, W, self.dim, self.heads, self.ws, self.shift, self.scale)
         y = ops.linear(a, self.proj, res=x)
         if self.mlp is not None and ops.tok_enabled():
+            if tail is not None:
+                ops.tok_chain(y, self.mlp, res=y, tail=tail, want_f32=False)
+                return None
             return ops.tok_chain(y, self.mlp, res=y)
         if not pl:
             h = ops.linear(ops.layernorm(y, *self.n2), self.fc1, act=ACT_GELU)
@@ -69,7 +77,7 @@ class DRCT:
                 sw = _Swin(sd, f"layers.{i}.swin{j + 1}.", device, dim, h, ws, ws // 2 if j % 2 else 0)
                 adj = ops.pack_conv(sd[f"layers.{i}.adjust{j + 1}.weight"], sd[f"layers.{i}.adjust{j + 1}.bias"], device)
                 adj_t = ops.pack_tok_gemm(sd[f"layers.{i}.adjust{j + 1}.weight"], sd[f"layers.{i}.adjust{j + 1}.bias"], device) \
-                    if (j < 4 and ops.tok_gemm_ok(dim, gc)) else None
+                    if ops.tok_gemm_ok(dim, gc if j < 4 else self.embed) else None
                 blocks.append((sw, adj, adj_t))
             self.groups.append(blocks)
         self.tail = SRTail(sd, device)
@@ -89,6 +97,15 @@ class DRCT:
             buf = cat[cur]
             for j, (sw, adj, adj_t) in enumerate(blocks):
                 dim = E + gc * j
+                # the adjust convolution of the dense block as the tail of the Swin block's MLP kernel: the block output itself
+                # (only consumed by adjust) never reaches HBM.  adjust1-4: LeakyReLU(0.2) -> the 32 new channels of the
+                # concatenation; adjust5: x5 * 0.2 + x -> the next group's buffer  (drct_arch.py:292-301)
+                if adj_t is not None and sw.mlp is not None and ops.tok_enabled() and TAIL_FUSED:
+                    if j < 4:
+                        sw(buf[:, :dim], B, H, W, tail=dict(tg=adj_t, out=buf[:, dim:dim + gc], act=ACT_LRELU, slope=0.2))
+                    else:
+                        sw(buf[:, :dim], B, H, W, tail=dict(tg=adj_t, out=cat[1 - cur][:, :E], cscale=0.2, res=buf[:, :E]))
+                    continue
                 y = sw(buf[:, :dim], B, H, W)
                 if j < 4 and adj_t is not None and ops.tok_enabled():
                     ops.tok_gemm(y, adj_t, act=ACT_LRELU, slope=0.2, out=buf[:, dim:dim + gc])

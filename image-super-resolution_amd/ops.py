@@ -592,12 +592,36 @@ def tok_waves(M: int, KS1: int) -> int:
 
 
 def tok_chain(x2d, tc: TokChain, *, res=None, rscale=1.0, rvec=None, cvec=None, cscale=1.0, post_ln=None, eps2=1e-5,
-              res2=None, out=None, out_planes=None, want_f32=True):
+              res2=None, out=None, out_planes=None, want_f32=True, tail=None):
     """x2d [M, >=K] fp32 rows -> [M, N]:  y = (W2 act(W1 pre(x) + b1) + b2) * cvec * cscale + res * rvec * rscale;
     post_ln = (gamma, beta): out = LayerNorm(y) * gamma + beta (+ res2).  out_planes: True / a Planes -> also emit bf16
-    hi / lo planes (returns (out, planes), or only the planes when want_f32 is False)."""
+    hi / lo planes (returns (out, planes), or only the planes when want_f32 is False).
+    tail = dict(tg=TokGemm, out=[M, N3] view, act=, slope=, cscale=, res=, rscale=): a third linear layer on y inside the same
+    kernel (out3 = act(W3 y + b3) * cscale + res * rscale); y itself is only stored when want_f32 -- returns out3 (or (y, out3))."""
     assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.shape[1] >= tc.K
     M = x2d.shape[0]
+    if tail is not None:
+        tg, out3 = tail["tg"], tail["out"]
+        assert cvec is None and rvec is None and post_ln is None and out_planes is None and cscale == 1.0 and rscale == 1.0
+        assert tg.K == tc.N and not tg.pre_ln and out3.shape == (M, tg.N) and out3.stride(1) == 1
+        if out is None and want_f32:
+            out = torch.empty(M, tc.N, device=x2d.device)
+        r3 = tail.get("res")
+        prof = CONV_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.call("ffsr_tok_chain_tail_f32", _ptr(x2d), x2d.stride(0), _ptr(tc.w1), _ptr(tc.b1), _ptr(tc.w2), _ptr(tc.b2), _ptr(res),
+                 0 if res is None else res.stride(0), _ptr(out), 0 if out is None else out.stride(0), M, tc.K, tc.N, tc.steps, tc.mode,
+                 int(tc.pre_ln), tc.eps1, _ptr(tg.w1), _ptr(tg.b1), _ptr(r3), 0 if r3 is None else r3.stride(0), _ptr(out3),
+                 out3.stride(0), tg.N, tail.get("act", ACT_NONE), float(tail.get("slope", 0.0)), float(tail.get("cscale", 1.0)),
+                 float(tail.get("rscale", 1.0)), tok_waves(M, (tc.K + 31) // 32), _stream())
+        if prof is not None:
+            e1.record()
+            prof.append((e0, e1, 2.0 * M * (tc.K * tc.H + tc.H * tc.N + tc.N * tg.N), (M, tc.N, tc.K, 1, 3),
+                         4.0 * (M * tc.K + tc.H * tc.K + tc.N * tc.H + tg.N * tc.N + M * tg.N * (1 + (r3 is not None))
+                                + (M * tc.N if out is not None else 0))))
+        return out3 if out is None else (out, out3)
     if out_planes is True:
         out_planes = Planes(1, 1, M, tc.N, x2d.device)
     if out is None and (want_f32 or out_planes is None):

@@ -102,6 +102,17 @@ int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const float* b1,
                        int ldp, long long M, int K, int N, int steps, int mode, int pre_ln, float eps1, float eps2,
                        float cscale, float rscale, int waves, void* stream);
 
+/* ffsr_tok_chain_f32 followed, inside the same kernel, by a third linear layer applied to the chain's output row y while it
+ * is still in registers:   out3 = act3(W3 y + b3) * cscale3 + res3 * rscale3   ([M, ldo3], N3 columns).
+ * `out` may be NULL: y itself then never reaches HBM.  w3 / b3 in the ffsr_tok_gemm_f32 packing (pack_tok_gemm); act3: none /
+ * ReLU / LeakyReLU.  Requires ceil(K/32) == ceil(N/32).  Replaces, per block of DRCT's residual dense group, the Swin block's
+ * x + mlp(norm2(x)) AND the 1x1 "adjust" convolution that consumes it (drct_arch.py:292-301: adjust1..4 + LeakyReLU(0.2) write
+ * the 32 new channels of the dense concatenation; adjust5 * 0.2 + x closes the group). */
+int ffsr_tok_chain_tail_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                            const float* res, int ldr, float* out, int ldo, long long M, int K, int N, int steps, int mode,
+                            int pre_ln, float eps1, const void* w3, const float* b3, const float* res3, int ldr3, float* out3,
+                            int ldo3, int N3, int act3, float slope3, float cscale3, float rscale3, int waves, void* stream);
+
 /* Token-stationary single GEMM with the producer fused in front: per token row x [K] (fp32, row stride ldx)
  *     out = act( W1 . pre(x) + b1 ) * cvec * cscale       -> fp32 `out` [M, ldo] and / or bf16 hi / lo planes [M, ldp]
  * pre = identity or nn.LayerNorm's normalisation (affine part folded into W1 / b1 by the packer).  Same kernel family as

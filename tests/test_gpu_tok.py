@@ -143,3 +143,38 @@ def test_tok_gemm_with_layernorm_prologue(K, N, M, ln, bias, act):
         assert bool((back[:, N:] == 0).all())
         assert (back[:, :N] - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item()
     assert rel(got, want) < 3e-5
+
+
+@pytest.mark.parametrize("K,H,N3,M,act", [(180, 360, 32, 1000, 3), (244, 488, 32, 2051, 3), (308, 308, 180, 1500, 0), (276, 276, 32, 352 * 512 + 8, 3)])
+def test_mlp_with_adjust_tail(K, H, N3, M, act):
+    """the Swin MLP kernel with the dense block's adjust convolution as its tail (drct_arch.py:292-301): adjust1-4 + LeakyReLU(0.2)
+    write a 32-channel slice of the concatenation buffer, adjust5 * 0.2 + x the next group's input; the MLP output itself is only
+    stored on request"""
+    ops = mod("ops")
+    g = gen(K + M + N3)
+    wide = torch.randn(M, 308, generator=g) * 1.5 + 0.3
+    x = wide[:, :K]
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    w1, b1 = torch.randn(H, K, generator=g) / K ** 0.5, torch.randn(H, generator=g) * 0.1
+    w2, b2 = torch.randn(K, H, generator=g) / H ** 0.5, torch.randn(K, generator=g) * 0.1
+    w3, b3 = torch.randn(N3, K, generator=g) / K ** 0.5, torch.randn(N3, generator=g) * 0.1
+    xd = x.double()
+    y = xd + F.linear(F.gelu(F.linear(F.layer_norm(xd, (K,), gamma.double(), beta.double(), 1e-5), w1.double(), b1.double())), w2.double(), b2.double())
+    z = F.linear(y, w3.double(), b3.double())
+    want3 = F.leaky_relu(z, 0.2) if act == 3 else z * 0.2 + wide[:, :N3].double()
+    tc = ops.pack_tok_chain(w1, b1, w2, b2, DEV, mode=0, ln=(gamma, beta))
+    tg = ops.pack_tok_gemm(w3, b3, DEV)
+    wg = wide.to(DEV)
+    xg = wg[:, :K]
+    if act == 3:        # into a slice right of the input columns, everything else untouched
+        before = wg.clone()
+        out3 = wg[:, K:K + N3] if K + N3 <= 308 else torch.empty(M, N3, device=DEV)
+        r = ops.tok_chain(xg, tc, res=xg, tail=dict(tg=tg, out=out3, act=3, slope=0.2), want_f32=False)
+        assert r is out3
+        if K + N3 <= 308:
+            assert torch.equal(wg[:, :K], before[:, :K]) and torch.equal(wg[:, K + N3:], before[:, K + N3:])
+        assert rel(out3, want3) < 3e-5
+    else:
+        out3 = torch.empty(M, N3, device=DEV)
+        ygot, r = ops.tok_chain(xg, tc, res=xg, tail=dict(tg=tg, out=out3, cscale=0.2, res=wg[:, :N3]))
+        assert rel(ygot, y) < 3e-5 and rel(r, want3) < 3e-5
