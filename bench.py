@@ -376,14 +376,14 @@ def main():
     n_l, dom_ms, dom_flops, dom_bytes = fams[dom]
     ksym, kname = names[dom]
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if (h, w) == (H_LR, W_LR) and args.batch == 1 and os.path.exists(tfile):
         # PMC counters cannot be read from inside this process: the per-launch HBM bytes come from the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py; corrected as the
         # guide prescribes: FETCH_SIZE x2 on gfx950)
         ent = json.load(open(tfile)).get(ksym)
         if ent:
-            traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json"
+            traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r03_pmc_traffic.json"
     mean_s = dom_ms / 1e3 / n_l
     bytes_l, flops_l = dom_bytes / n_l, dom_flops / n_l
     gbps = bytes_l / mean_s / 1e9

@@ -16,7 +16,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(conv_gemm_\w+_kernel|conv_gemm_kernel|conv3_strip_planes_kernel)", r["Kernel_Name"])
+            m = re.search(r"(conv_gemm_\w+_kernel|conv_gemm_kernel|conv3_strip_planes_kernel|tok_chain_kernel)", r["Kernel_Name"])
             if not m:
                 continue
             a = acc[m.group(1)]
