@@ -91,12 +91,14 @@ __global__ void modulate_kernel(const float* __restrict__ t_lr, int ldt, const f
 }
 
 // phases 5b + 5c + 6 (enhanced_fusion_v2.py:735-774).  fw = [W1 16x3 | b1 16 | W2 4x16 | b2 4] of freq_weight_conv.
+// Improvement flags (io.py:186-193): fw == NULL (multi_resolution_fusion off) -> `hier` IS the fused image (simple_fusion's
+// output), no frequency-guided part; gates == NULL (dynamic_expert_selection off) -> phase 6 is skipped.
 __global__ void route_kernel(const float* __restrict__ enh, int lde, const float* __restrict__ hier, int ldh,
                              const float* __restrict__ routing, int ldr, const float* __restrict__ fw,
                              const float* __restrict__ gates, int ldg, const float* __restrict__ diff, int ldd,
                              float* __restrict__ out, int ldo, int B, int h, int w, int Hh, int Wh, float sh, float sw) {
   __shared__ float F[132];
-  if (threadIdx.x < 132) F[threadIdx.x] = fw[threadIdx.x];
+  if (fw && threadIdx.x < 132) F[threadIdx.x] = fw[threadIdx.x];
   __syncthreads();
   long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long long)B * Hh * Wh) return;
@@ -106,32 +108,39 @@ __global__ void route_kernel(const float* __restrict__ enh, int lde, const float
   const Bil bl = make_bil(y, x, h, w, sh, sw);
   const size_t lrb = (size_t)b * h * w;
   // frequency-guided expert weights
-  float r[3];
+  float wt[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fw) {
+    float r[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) r[c] = sample(routing + lrb * ldr, ldr, w, bl, c);
-  float lg[4] = {F[128], F[129], F[130], F[131]};
+    for (int c = 0; c < 3; ++c) r[c] = sample(routing + lrb * ldr, ldr, w, bl, c);
+    float lg[4] = {F[128], F[129], F[130], F[131]};
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float hdn = gelu(F[48 + j] + F[j * 3] * r[0] + F[j * 3 + 1] * r[1] + F[j * 3 + 2] * r[2]);
+    for (int j = 0; j < 16; ++j) {
+      const float hdn = gelu(F[48 + j] + F[j * 3] * r[0] + F[j * 3 + 1] * r[1] + F[j * 3 + 2] * r[2]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) lg[e] = fmaf(F[64 + e * 16 + j], hdn, lg[e]);
+      for (int e = 0; e < 4; ++e) lg[e] = fmaf(F[64 + e * 16 + j], hdn, lg[e]);
+    }
+    const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    float ws = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wt[e] = expf(lg[e] - mx);
+      ws += wt[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wt[e] /= ws;
   }
-  const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
-  float wt[4], ws = 0.f;
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, gs = 1.f, bw = 0.f;
+  if (gates) {
+    gs = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    wt[e] = expf(lg[e] - mx);
-    ws += wt[e];
+    for (int e = 0; e < 4; ++e) {
+      g[e] = sample(gates + lrb * ldg, ldg, w, bl, e);
+      gs += g[e];
+    }
+    gs += 1e-8f;
+    bw = 0.3f + 0.4f * sample(diff + lrb * ldd, ldd, w, bl, 0);
   }
-  float g[4], gs = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    wt[e] /= ws;
-    g[e] = sample(gates + lrb * ldg, ldg, w, bl, e);
-    gs += g[e];
-  }
-  gs += 1e-8f;
-  const float bw = 0.3f + 0.4f * sample(diff + lrb * ldd, ldd, w, bl, 0);
   const float* ep = enh + pix * lde;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -142,13 +151,14 @@ __global__ void route_kernel(const float* __restrict__ enh, int lde, const float
       fq += v * wt[e];
       dy += v * g[e];
     }
-    const float fused = hier[pix * ldh + c] * 0.7f + fq * 0.3f;
-    out[pix * ldo + c] = (1.f - bw) * fused + bw * (dy / gs);
+    const float fused = fw ? hier[pix * ldh + c] * 0.7f + fq * 0.3f : hier[pix * ldh + c];
+    out[pix * ldo + c] = gates ? (1.f - bw) * fused + bw * (dy / gs) : fused;
   }
   out[pix * ldo + 3] = 0.f;
 }
 
 // enhanced = clamp(sr + gate * strength * edge, 0, 1); out = clamp(enhanced + rscale * bilinear(lr), 0, 1)
+// edge == NULL (edge_enhancement off): enhanced = sr
 __global__ void edge_final_kernel(const float* __restrict__ sr, int lds, const float* __restrict__ edge, int lde,
                                   const float* __restrict__ gate, int ldg, const float* __restrict__ strength,
                                   const float* __restrict__ lr, int ldl, const float* __restrict__ rscale, float* __restrict__ out,
@@ -159,12 +169,15 @@ __global__ void edge_final_kernel(const float* __restrict__ sr, int lds, const f
   long long t = pix / Wh;
   const int y = (int)(t % Hh), b = (int)(t / Hh);
   const Bil bl = make_bil(y, x, h, w, sh, sw);
-  const float gs = gate[pix * ldg] * strength[0];
+  const float gs = edge ? gate[pix * ldg] * strength[0] : 0.f;
   const float rs = rscale[0];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float v = sr[pix * lds + c] + gs * edge[pix * lde + c];
-    v = fminf(fmaxf(v, 0.f), 1.f);
+    float v = sr[pix * lds + c];
+    if (edge) {
+      v += gs * edge[pix * lde + c];
+      v = fminf(fmaxf(v, 0.f), 1.f);
+    }
     v += rs * sample(lr + (size_t)b * h * w * ldl, ldl, w, bl, c);
     out[pix * ldo + c] = fminf(fmaxf(v, 0.f), 1.f);
   }
@@ -209,7 +222,7 @@ extern "C" int ffsr_modulate_f32(const float* t_lr, int ldt, const float* w2, co
 extern "C" int ffsr_fusion_route_f32(const float* enh, int lde, const float* hier, int ldh, const float* routing, int ldr,
                                      const float* fw, const float* gates, int ldg, const float* diff, int ldd, float* out,
                                      int ldo, int B, int h, int w, int Hh, int Wh, void* stream) {
-  FFSR_CHECK(enh && hier && routing && fw && gates && diff && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0 && ldo >= 4);
+  FFSR_CHECK(enh && hier && (routing || !fw) && (!gates == !diff) && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0 && ldo >= 4);
   FFSR_LAUNCH(route_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, enh, lde, hier, ldh, routing, ldr,
                      fw, gates, ldg, diff, ldd, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
   return ffsr_launch_status();
@@ -218,7 +231,7 @@ extern "C" int ffsr_fusion_route_f32(const float* enh, int lde, const float* hie
 extern "C" int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, const float* gate, int ldg,
                                    const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo,
                                    int B, int h, int w, int Hh, int Wh, void* stream) {
-  FFSR_CHECK(sr && edge && gate && strength && lr && rscale && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0);
+  FFSR_CHECK(sr && (!edge || (gate && strength)) && lr && rscale && out && B > 0 && h > 0 && w > 0 && Hh > 0 && Wh > 0);
   FFSR_LAUNCH(edge_final_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0, ST, sr, lds, edge, lde, gate, ldg,
                      strength, lr, ldl, rscale, out, ldo, B, h, w, Hh, Wh, (float)h / (float)Hh, (float)w / (float)Wh);
   return ffsr_launch_status();

@@ -29,7 +29,8 @@ def require_gpu(device) -> torch.device:
 
 
 class Engine:
-    def __init__(self, weights: Dict[str, dict], device=None, scale=4):
+    def __init__(self, weights: Dict[str, dict], device=None, scale=4, fusion_flags=None):
+        """fusion_flags: model.fusion.improvements of configs/train_config.yaml (io.py:186-193); None = all enabled."""
         self.device = require_gpu(device)
         self.scale = scale
         # weight preparation (packing, BN folding, bias tables) runs as torch ops on whatever device the tensors already
@@ -42,7 +43,7 @@ class Engine:
             self.grl = GRL(weights["grl"], self.device)
             self.nafnet = NAFNetSR(weights["nafnet"], self.device, scale)
             self.mamba = MambaIR(weights["mamba"], self.device)
-            self.fusion = FusionNet(weights["fusion"], self.device, scale)
+            self.fusion = FusionNet(weights["fusion"], self.device, scale, fusion_flags)
             self.concurrent_experts = os.environ.get("FFSR_CONCURRENT_EXPERTS", "1") != "0"
             # two "lanes" (a main stream + four expert streams each): consecutive images may be submitted to alternate
             # lanes so that the latency-bound kernels of one image fill the gaps of the other (process(..., lane=i % 2))

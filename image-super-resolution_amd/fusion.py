@@ -11,6 +11,10 @@ Same state_dict keys as the reference.  GPU-first re-organisation (results uncha
 * concatenations are channel slices of pre-allocated buffers (producers write in place);
 * phase 4's 1x1 conv (128->32) is applied before the bilinear upsample (both linear), the HR-resolution
   modulation / routing / gating / final residual are fused elementwise kernels.
+
+The six improvement switches of configs/train_config.yaml (model.fusion.improvements -> the enable_* arguments,
+io.py:186-193) select the same alternative branches as _run_pipeline :696-786: a disabled improvement's sub-module is
+neither expected in the state_dict nor run.
 """
 from __future__ import annotations
 
@@ -21,6 +25,7 @@ import torch
 from . import ops
 from .common import dev, tokens
 from .ops import ACT_GELU, ACT_RELU, ACT_SIGMOID
+from .weights import improvement_flags
 
 EXPERTS = ("drct", "grl", "nafnet", "mamba")
 
@@ -72,9 +77,33 @@ class _MHA:
 
 
 class FusionNet:
-    def __init__(self, sd, device, scale=4):
+    def __init__(self, sd, device, scale=4, flags=None):
         self.device, self.scale = device, scale
+        self.flags = improvement_flags(flags)
+        on = self.flags.get
         g = lambda k: sd[k].float()
+        self.refine = [ops.pack_conv(sd[f"refine.{i}.weight"], sd[f"refine.{i}.bias"], device, cin_pad=4 if i == 0 else None)
+                       for i in range(0, 12, 2)]
+        self.residual_scale = dev(g("residual_scale").reshape(1), device)
+        self._fft_cache = {}
+        if on("adaptive_frequency_bands"):
+            self._init_bands(sd, device, g)
+        # without the bands phase 3 has nothing to enhance: routing = the LR image (enhanced_fusion_v2.py:706-718)
+        self.use_cross_band = on("cross_band_attention") and on("adaptive_frequency_bands")
+        if self.use_cross_band:
+            self._init_cross_band(sd, device, g)
+        if on("collaborative_learning"):
+            self._init_collaborative(sd, device, g)
+        if on("multi_resolution_fusion"):
+            self._init_multi_res(sd, device, g)
+        else:
+            self.simple = ops.pack_conv(sd["simple_fusion.weight"], sd["simple_fusion.bias"], device)
+        if on("dynamic_expert_selection"):
+            self._init_selector(sd, device, g)
+        if on("edge_enhancement"):
+            self._init_edge(sd, device, g)
+
+    def _init_bands(self, sd, device, g):
         # ---- phase 2
         self.dct_D = dev(g("freq_decomp.dct.dct_basis"), device)
         self.dct_masks = dev(torch.stack([g("freq_decomp.dct.low_mask"), g("freq_decomp.dct.mid_mask"),
@@ -88,7 +117,8 @@ class FusionNet:
         self.fft_logits = logits.to(device)[..., :1]
         self.fft_temp = max(float(g("freq_decomp.fft.temperature")), 1.0)
         self.fft_scale = dev(g("freq_decomp.fft.band_scale"), device)
-        self._fft_cache = {}
+
+    def _init_cross_band(self, sd, device, g):
         # ---- phase 3
         p = "cross_band."
         self.band_proj = ops.pack_conv(sd[p + "band_proj.weight"], sd[p + "band_proj.bias"], device, cin_pad=4)
@@ -96,6 +126,8 @@ class FusionNet:
         self.cb_mha = _MHA(sd, p + "band_attention.", device, 4)
         self.cb_lka = _LKABlock(sd, p + "lka_block.", device)
         self.cb_out = ops.pack_conv(sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], device)
+
+    def _init_collaborative(self, sd, device, g):
         # ---- phase 4
         p = "collaborative."
         self.align = {n: ops.pack_conv(sd[f"{p}align_layers.{n}.weight"], sd[f"{p}align_layers.{n}.bias"], device)
@@ -109,6 +141,8 @@ class FusionNet:
         self.mod0 = [ops.pack_conv(sd[f"{p}modulation.{i}.0.weight"], sd[f"{p}modulation.{i}.0.bias"], device) for i in range(4)]
         self.mod2 = [(dev(g(f"{p}modulation.{i}.2.weight").reshape(3, 32), device), dev(g(f"{p}modulation.{i}.2.bias"), device))
                      for i in range(4)]
+
+    def _init_multi_res(self, sd, device, g):
         # ---- phase 5
         p = "multi_res."
         pc = lambda k, **kw: ops.pack_conv(sd[p + k + ".weight"], sd.get(p + k + ".bias"), device, **kw)
@@ -121,16 +155,16 @@ class FusionNet:
         self.rgb0, self.rgb2 = pc("to_rgb.0"), pc("to_rgb.2")
         self.fw = dev(torch.cat([g("freq_weight_conv.0.weight").reshape(-1), g("freq_weight_conv.0.bias"),
                                  g("freq_weight_conv.2.weight").reshape(-1), g("freq_weight_conv.2.bias")]), device)
+
+    def _init_selector(self, sd, device, g):
         # ---- phase 6
         p = "dynamic_selector."
         pc = lambda k, **kw: ops.pack_conv(sd[p + k + ".weight"], sd.get(p + k + ".bias"), device, **kw)
         self.dn = [pc("difficulty_net.0", cin_pad=4), pc("difficulty_net.2"), pc("difficulty_net.4")]
         self.gn = [pc("gate_net.0", cin_pad=4), pc("gate_net.2"), pc("gate_net.4")]
         self.temperature = dev(g(p + "temperature").reshape(1), device)
-        # ---- phase 7
-        self.refine = [ops.pack_conv(sd[f"refine.{i}.weight"], sd[f"refine.{i}.bias"], device, cin_pad=4 if i == 0 else None)
-                       for i in range(0, 12, 2)]
-        self.residual_scale = dev(g("residual_scale").reshape(1), device)
+
+    def _init_edge(self, sd, device, g):
         # ---- phase 7b
         p = "edge_enhance."
         pc = lambda k, **kw: ops.pack_conv(sd[p + k + ".weight"], sd.get(p + k + ".bias"), device, **kw)
@@ -152,7 +186,8 @@ class FusionNet:
         """Build (once per image size) the cached input-independent tables on the CURRENT stream and make every later user
         wait for them: the cache entry carries an event that `_fft_tables` makes the consuming stream wait on, so a hit
         from another stream lane (or from a side stream) can never read a table that is still being written."""
-        self._fft_tables(h, w)
+        if self.flags["adaptive_frequency_bands"]:
+            self._fft_tables(h, w)
 
     def _fft_tables(self, h, w):
         key = (h, w)
@@ -289,9 +324,9 @@ class FusionNet:
     def lr_phases(self, lr):
         """The part of the pipeline that needs only the LR image: phase 2 (bands), phase 3 (cross-band routing) and the
         selector's gates of phase 6.  The engine runs it on a side stream while the four experts compute."""
-        bands = self.frequency_bands(lr)
-        routing = self.cross_band_routing(bands)
-        gates, diff = self.selector(routing)
+        bands = self.frequency_bands(lr) if self.flags["adaptive_frequency_bands"] else None
+        routing = self.cross_band_routing(bands) if self.use_cross_band else lr
+        gates, diff = self.selector(routing) if self.flags["dynamic_expert_selection"] else (None, None)
         return bands, routing, gates, diff
 
     def __call__(self, lr, imgs, feats, return_stages=False, pre=None):
@@ -302,10 +337,18 @@ class FusionNet:
         bands, routing, gates, diff = pre if pre is not None else self.lr_phases(lr)
         cat3 = torch.empty(B, Hh, Wh, 76, device=self.device)
         enh = cat3[..., 64:76]
-        self.collaborative(feats, imgs, enh)
-        hier = self.hierarchical(cat3)
+        if self.flags["collaborative_learning"]:
+            self.collaborative(feats, imgs, enh)
+        else:                                                   # the expert images themselves are fused (:721-726)
+            for e, n in enumerate(EXPERTS):
+                ops.unary(imgs[n], out=enh[..., 3 * e:3 * e + 3])
         fused = torch.empty(B, Hh, Wh, 4, device=self.device)
-        ops.fusion_route(enh, hier, routing, self.fw, gates, diff, fused)
+        if self.flags["multi_resolution_fusion"]:
+            hier = self.hierarchical(cat3)
+            ops.fusion_route(enh, hier, routing, self.fw, gates, diff, fused)
+        else:                                                   # simple_fusion: 1x1 conv over the 12 stacked channels (:748-750)
+            hier = ops.conv2d(enh, self.simple)
+            ops.fusion_route(enh, hier, routing, None, gates, diff, fused)
         if ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3":   # the whole 6-conv stack runs on bf16 hi/lo planes
             r = ops.split_planes(fused[..., :3])
             thin = ops.thin3_ok(self.refine[-1], B * Hh * Wh)        # the 128 -> 3 head reads an fp32 map
@@ -318,7 +361,10 @@ class FusionNet:
                 r = ops.conv2d(r, cv, act=ACT_GELU)
         refined = ops.conv2d(r, self.refine[-1], res=fused[..., :3], cscale=0.1)
         out = ops.new_map(B, Hh, Wh, 3, self.device)
-        self.laplacian_refine(refined, lr, out)
+        if self.flags["edge_enhancement"]:
+            self.laplacian_refine(refined, lr, out)
+        else:
+            ops.edge_final(refined, None, None, None, lr, self.residual_scale, out)
         if return_stages:
             return out, dict(bands=bands, routing=routing, enh=enh, hier=hier, fused=fused, refined=refined)
         return out

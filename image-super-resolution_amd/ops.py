@@ -951,14 +951,16 @@ def fusion_route(enh, hier, routing, fw, gates, diff, out):
     B, Hh, Wh, _ = enh.shape
     _, h, w, _ = routing.shape
     hip.call("ffsr_fusion_route_f32", _ptr(enh), ld(enh), _ptr(hier), ld(hier), _ptr(routing), ld(routing), _ptr(fw),
-             _ptr(gates), ld(gates), _ptr(diff), ld(diff), _ptr(out), ld(out), B, h, w, Hh, Wh, _stream())
+             _ptr(gates), 0 if gates is None else ld(gates), _ptr(diff), 0 if diff is None else ld(diff), _ptr(out), ld(out),
+             B, h, w, Hh, Wh, _stream())
 
 
 def edge_final(sr, edge, gate, strength, lr, rscale, out):
     B, Hh, Wh, _ = sr.shape
     _, h, w, _ = lr.shape
-    hip.call("ffsr_edge_final_f32", _ptr(sr), ld(sr), _ptr(edge), ld(edge), _ptr(gate), ld(gate), _ptr(strength),
-             _ptr(lr), ld(lr), _ptr(rscale), _ptr(out), ld(out), B, h, w, Hh, Wh, _stream())
+    hip.call("ffsr_edge_final_f32", _ptr(sr), ld(sr), _ptr(edge), 0 if edge is None else ld(edge), _ptr(gate),
+             0 if gate is None else ld(gate), _ptr(strength), _ptr(lr), ld(lr), _ptr(rscale), _ptr(out), ld(out), B, h, w, Hh, Wh,
+             _stream())
 
 
 # ---------------------------------------------------------------------------------------------- image boundary

@@ -218,7 +218,27 @@ def zigzag_masks(n=8):
     return (order < lo).float(), ((order >= lo) & (order < hi)).float(), (order >= hi).float()
 
 
-def fusion_state_dict(seed=5) -> SD:
+IMPROVEMENTS = ("dynamic_expert_selection", "cross_band_attention", "adaptive_frequency_bands", "multi_resolution_fusion",
+                "collaborative_learning", "edge_enhancement")
+# sub-modules CompleteEnhancedFusionSR does not construct when the improvement is off (enhanced_fusion_v2.py:527-590)
+_IMPROVEMENT_MODULES = {"dynamic_expert_selection": ("dynamic_selector.",), "cross_band_attention": ("cross_band.",),
+                        "adaptive_frequency_bands": ("freq_decomp.",), "multi_resolution_fusion": ("multi_res.", "freq_weight_conv."),
+                        "collaborative_learning": ("collaborative.",), "edge_enhancement": ("edge_enhance.",)}
+
+
+def improvement_flags(flags=None) -> Dict[str, bool]:
+    """{improvement: bool} with the reference's defaults (all True, io.py:186-193) for names the caller left out."""
+    flags = dict(flags or {})
+    unknown = set(flags) - set(IMPROVEMENTS)
+    if unknown:
+        raise ValueError(f"unknown fusion improvement(s) {sorted(unknown)}; the reference knows {list(IMPROVEMENTS)}")
+    return {k: bool(flags.get(k, True)) for k in IMPROVEMENTS}
+
+
+def fusion_state_dict(seed=5, flags=None) -> SD:
+    """flags: model.fusion.improvements of configs/train_config.yaml; a disabled improvement's sub-module is left out and
+    multi_resolution_fusion=False adds the `simple_fusion` 1x1 convolution instead (enhanced_fusion_v2.py:549-560)."""
+    flags = improvement_flags(flags)
     I = _Init(seed)
     I.const("residual_scale", 0.1)
     p = "freq_decomp."
@@ -322,11 +342,16 @@ def fusion_state_dict(seed=5) -> SD:
     I.conv(p + "fusion.2", 3, 32, 3)
     I.conv(p + "edge_gate.0", 16, 6, 3)
     I.conv(p + "edge_gate.2", 1, 16, 3)
-    return I.sd
+    I.conv("simple_fusion", 3, 12, 1)            # drawn last: the other tensors do not depend on the flags
+    drop = tuple(q for k, on in flags.items() if not on for q in _IMPROVEMENT_MODULES[k])
+    if flags["multi_resolution_fusion"]:
+        drop += ("simple_fusion.",)
+    return {k: v for k, v in I.sd.items() if not k.startswith(drop)} if drop else I.sd
 
 
-def random_weights(seed=0, small=False, shapes_only=False) -> Dict[str, SD]:
+def random_weights(seed=0, small=False, shapes_only=False, fusion_flags=None) -> Dict[str, SD]:
     """All five state_dicts.  small=True: reduced-depth experts of the real width for smoke tests.
+    fusion_flags: the fusion network's improvement switches (see fusion_state_dict).
     shapes_only=True: same keys and shapes, but the randomly initialised tensors are meta tensors (no storage) --
     the key/shape template load_model_dir and broadcast_weights need, without 184 M random numbers."""
     global _SHAPES_ONLY
@@ -335,10 +360,10 @@ def random_weights(seed=0, small=False, shapes_only=False) -> Dict[str, SD]:
         if small:
             return {"drct": drct_state_dict(seed + 1, groups=1), "grl": grl_state_dict(seed + 2, depths=(2,)),
                     "nafnet": nafnet_state_dict(seed + 3, width=64, enc=(1, 1, 1, 1), mid=1, dec=(1, 1, 1, 1)),
-                    "mamba": mambair_state_dict(seed + 4, depths=(1,)), "fusion": fusion_state_dict(seed + 5)}
+                    "mamba": mambair_state_dict(seed + 4, depths=(1,)), "fusion": fusion_state_dict(seed + 5, fusion_flags)}
         return {"drct": drct_state_dict(seed + 1), "grl": grl_state_dict(seed + 2),
                 "nafnet": nafnet_state_dict(seed + 3), "mamba": mambair_state_dict(seed + 4),
-                "fusion": fusion_state_dict(seed + 5)}
+                "fusion": fusion_state_dict(seed + 5, fusion_flags)}
     finally:
         _SHAPES_ONLY = prev
 

@@ -279,12 +279,16 @@ int ffsr_modulate_f32(const float* t_lr, int ldt, const float* w2, const float* 
 /* Phases 5b + 5c + 6 fused at HR (enhanced_fusion_v2.py:735-774): enh [.., 12] = 4 enhanced expert images,
  * hier [.., 3] = sigmoid output of the hierarchical fusion, routing [B,h,w,ldr] = routing_lr,
  * fw = freq_weight_conv packed [W1 16x3 | b1 16 | W2 4x16 | b2 4], gates [B,h,w,4], diff [B,h,w,1] at LR.
- * out [.., 4] = (1 - bw) * (0.7 hier + 0.3 freq_fused) + bw * dynamic_fused, channel 3 zeroed. */
+ * out [.., 4] = (1 - bw) * (0.7 hier + 0.3 freq_fused) + bw * dynamic_fused, channel 3 zeroed.
+ * Improvement switches (io.py:186-193 / enhanced_fusion_v2.py:729-774): fw == NULL (multi_resolution_fusion off) -> `hier`
+ * is simple_fusion's output and is taken as the fused image; gates == diff == NULL (dynamic_expert_selection off) -> no
+ * dynamic blend.  `routing` gives the LR size and may be the LR image itself. */
 int ffsr_fusion_route_f32(const float* enh, int lde, const float* hier, int ldh, const float* routing, int ldr,
                           const float* fw, const float* gates, int ldg, const float* diff, int ldd, float* out, int ldo,
                           int B, int h, int w, int Hh, int Wh, void* stream);
 /* out = clamp(clamp(sr + gate * strength * edge, 0, 1) + rscale * bilinear(lr), 0, 1): edge_enhancement.py:261-262 and
- * enhanced_fusion_v2.py:788-795.  gate [.., 1] already sigmoid-ed; strength, rscale = device scalars. */
+ * enhanced_fusion_v2.py:788-795.  gate [.., 1] already sigmoid-ed; strength, rscale = device scalars.
+ * edge == NULL (edge_enhancement off, :784-786): out = clamp(sr + rscale * bilinear(lr), 0, 1). */
 int ffsr_edge_final_f32(const float* sr, int lds, const float* edge, int lde, const float* gate, int ldg,
                         const float* strength, const float* lr, int ldl, const float* rscale, float* out, int ldo, int B,
                         int h, int w, int Hh, int Wh, void* stream);

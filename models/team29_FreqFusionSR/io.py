@@ -70,8 +70,10 @@ def _rank_device(device):
     return device
 
 
-def _load_engine(model_dir, device):
-    scale = SCALE
+def _read_config():
+    """-> (scale, improvement flags) of configs/train_config.yaml (io.py:174-193); flags name only the six improvements the
+    reference reads (improvements.get(name, True)) -- other entries are ignored there and here."""
+    scale, flags = SCALE, {}
     if os.path.exists(CONFIG_PATH):
         with open(CONFIG_PATH) as f:
             cfg = yaml.safe_load(f) or {}
@@ -84,17 +86,21 @@ def _load_engine(model_dir, device):
                 raise ValueError(f"configs/train_config.yaml model.fusion.{k}={fusion_cfg[k]} is not the submitted "
                                  f"architecture ({v}) this engine implements")
         # the reference builds a different network when an improvement is switched off (io.py:186-193 ->
-        # CompleteEnhancedFusionSR(enable_*=...)); this engine implements the submitted one: all six enabled
-        for k, v in (fusion_cfg.get("improvements") or {}).items():
-            if v is not True:
-                raise ValueError(f"configs/train_config.yaml model.fusion.improvements.{k}={v!r}: this engine implements "
-                                 "the submitted architecture with every improvement enabled")
+        # CompleteEnhancedFusionSR(enable_*=...)); so does the engine (fusion.FusionNet(flags=...))
+        given = fusion_cfg.get("improvements") or {}
+        flags = {k: bool(given[k]) for k in _pkg("weights").IMPROVEMENTS if k in given}
+    return scale, _pkg("weights").improvement_flags(flags)
+
+
+def _load_engine(model_dir, device):
+    scale, flags = _read_config()
     weights, shard, engine = _pkg("weights"), _pkg("shard"), _pkg("engine")
     rank, world = shard.init_process_group()
-    templates = weights.random_weights(shapes_only=True)      # keys + shapes; values come from the files (rank 0)
-    w = weights.load_model_dir(model_dir, templates, weights.random_weights) if rank == 0 else templates
+    templates = weights.random_weights(shapes_only=True, fusion_flags=flags)   # keys + shapes; values come from the files (rank 0)
+    defaults = lambda: weights.random_weights(fusion_flags=flags)
+    w = weights.load_model_dir(model_dir, templates, defaults) if rank == 0 else templates
     w = shard.broadcast_weights(w, device)
-    return engine.Engine(w, device, scale), rank, world
+    return engine.Engine(w, device, scale, fusion_flags=flags), rank, world
 
 
 WORKER_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "worker.py")

@@ -202,33 +202,50 @@ def laplacian_refine(sd, img, p="edge_enhance.", levels=3):
 
 
 # ------------------------------------------------------------------ whole pipeline
-def fusion_forward(sd, lr, imgs, feats, scale=4, return_stages=False, train=False):
+ALL_IMPROVEMENTS = ("dynamic_expert_selection", "cross_band_attention", "adaptive_frequency_bands", "multi_resolution_fusion",
+                    "collaborative_learning", "edge_enhancement")
+
+
+def fusion_forward(sd, lr, imgs, feats, scale=4, return_stages=False, train=False, flags=None):
     """lr [B,3,h,w]; imgs/feats: dicts keyed drct/grl/nafnet/mamba -> final SR [B,3,4h,4w] in [0,1].
     train=True: model.train() semantics with dropout off -- BatchNorm batch statistics (running statistics in ``sd``
     updated in place), no clamp after the collaborative modulation and none on the result
-    (large_kernel_attention.py:420-423, enhanced_fusion_v2.py:792-795); differentiable w.r.t. the tensors of ``sd``."""
+    (large_kernel_attention.py:420-423, enhanced_fusion_v2.py:792-795); differentiable w.r.t. the tensors of ``sd``.
+    flags: {improvement name: bool} of configs/train_config.yaml model.fusion.improvements (io.py:186-193 -> the enable_*
+    arguments of CompleteEnhancedFusionSR); a disabled improvement takes the branch of _run_pipeline :696-786 that skips it."""
+    on = lambda k: True if flags is None else bool(flags.get(k, True))
     B, _, h, w = lr.shape
     HR = (h * scale, w * scale)
     stages = {}
-    bands = frequency_bands(sd, lr)
-    ebands = cross_band(sd, bands, train=train)
-    routing = ebands[0] + ebands[1] + ebands[2]
-    enh = collaborative(sd, feats, [imgs[n] for n in EXPERTS], train=train)
-    hier = hierarchical(sd, enh)
-    logits = conv(sd, "freq_weight_conv.2", F.gelu(conv(sd, "freq_weight_conv.0", bilinear(routing, HR))))
-    wts = logits.softmax(1)
-    freq = sum(e * wts[:, i:i + 1] for i, e in enumerate(enh))
-    fused = hier * 0.7 + freq * 0.3
-    gates, diff = dynamic_selector(sd, routing)
-    g_hr = bilinear(gates, HR)
-    dyn = sum(e * g_hr[:, i:i + 1] for i, e in enumerate(enh)) / (g_hr.sum(1, keepdim=True) + 1e-8)
-    bw = 0.3 + 0.4 * bilinear(diff, HR)
-    fused = (1 - bw) * fused + bw * dyn
+    bands = frequency_bands(sd, lr) if on("adaptive_frequency_bands") else None
+    ebands, routing = bands, lr
+    if on("cross_band_attention") and bands is not None:
+        ebands = cross_band(sd, bands, train=train)
+        routing = ebands[0] + ebands[1] + ebands[2]
+    if on("collaborative_learning"):
+        enh = collaborative(sd, feats, [imgs[n] for n in EXPERTS], train=train)
+    else:
+        enh = [imgs[n] for n in EXPERTS]
+    hier = None
+    if on("multi_resolution_fusion"):
+        hier = hierarchical(sd, enh)
+        logits = conv(sd, "freq_weight_conv.2", F.gelu(conv(sd, "freq_weight_conv.0", bilinear(routing, HR))))
+        wts = logits.softmax(1)
+        freq = sum(e * wts[:, i:i + 1] for i, e in enumerate(enh))
+        fused = hier * 0.7 + freq * 0.3
+    else:
+        fused = conv(sd, "simple_fusion", torch.cat(enh, 1))
+    if on("dynamic_expert_selection"):
+        gates, diff = dynamic_selector(sd, routing)
+        g_hr = bilinear(gates, HR)
+        dyn = sum(e * g_hr[:, i:i + 1] for i, e in enumerate(enh)) / (g_hr.sum(1, keepdim=True) + 1e-8)
+        bw = 0.3 + 0.4 * bilinear(diff, HR)
+        fused = (1 - bw) * fused + bw * dyn
     r = fused
     for i in range(0, 10, 2):
         r = F.gelu(conv(sd, f"refine.{i}", r, 1))
     fused = fused + 0.1 * conv(sd, "refine.10", r, 1)
-    edged = laplacian_refine(sd, fused)
+    edged = laplacian_refine(sd, fused) if on("edge_enhancement") else fused
     out = edged + sd["residual_scale"] * bilinear(lr, HR)
     if not train:
         out = out.clamp(0, 1)

@@ -333,8 +333,47 @@ def golden_train():
     print(f"  fusion_train.pt: {os.path.getsize(os.path.join(GOLDEN, 'fusion_train.pt')) / 1e6:.2f} MB, loss {loss.item():.6f}")
 
 
+FLAG_ARGS = {"dynamic_expert_selection": "enable_dynamic_selection", "cross_band_attention": "enable_cross_band_attn",
+             "adaptive_frequency_bands": "enable_adaptive_bands", "multi_resolution_fusion": "enable_multi_resolution",
+             "collaborative_learning": "enable_collaborative", "edge_enhancement": "enable_edge_enhance"}
+
+
+def golden_flags():
+    """VERDICT r2 missing #5: the network the reference builds when configs/train_config.yaml switches an improvement off
+    (io.py:186-193 -> CompleteEnhancedFusionSR(enable_*=False)).  For each single improvement off, and all off, the REFERENCE's
+    forward_with_precomputed on the 32x32 case -> tests/golden/fusion_flags.pt.  Weights = fusion_full.pt's state_dict for the
+    modules that exist in the variant (not stored again) + the variant-only `simple_fusion` 1x1 convolution (stored, 39 values)."""
+    ref = load_reference()
+    full = load_sd(os.path.join(GOLDEN, "fusion_full.pt"))
+    g = torch.Generator().manual_seed(90)
+    simple = {"simple_fusion.weight": (torch.randn(3, 12, 1, 1, generator=g) * 0.3).half().float(),
+              "simple_fusion.bias": (torch.randn(3, generator=g) * 0.05).half().float()}
+    lr = lr_input(41, 1, 32, 32)
+    bic = torch.nn.functional.interpolate(lr, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    imgs = {n: (bic + 0.03 * torch.randn(bic.shape, generator=g)).clamp(0, 1).half().float() for n in fusion.EXPERTS}
+    feats = {n: torch.randn(1, 64 if n == "nafnet" else 180, 32, 32, generator=g).half().float() for n in fusion.EXPERTS}
+    variants = [{k: (k != off) for k in FLAG_ARGS} for off in FLAG_ARGS] + [{k: False for k in FLAG_ARGS}]
+    outs = []
+    for flags in variants:
+        m = ref.CompleteEnhancedFusionSR(expert_ensemble=None, **{FLAG_ARGS[k]: v for k, v in flags.items()}).eval()
+        sd = dict(full)
+        sd.update(simple)
+        missing = m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()}, strict=False)
+        assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+        with torch.no_grad():
+            want = m.forward_with_precomputed(lr, imgs, feats)
+            got = fusion.fusion_forward(sd, lr, imgs, feats, flags=flags)
+        off = [k for k, v in flags.items() if not v]
+        report(f"fusion with {off} off", got, want, 2e-5)
+        outs.append({"flags": flags, "out": want, "keys": sorted(k for k in m.state_dict() if not k.endswith("num_batches_tracked"))})
+    torch.save({"lr": lr, "imgs": {k: v.half() for k, v in imgs.items()}, "feats": {k: v.half() for k, v in feats.items()},
+                "simple": simple, "variants": outs}, os.path.join(GOLDEN, "fusion_flags.pt"))
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["inference", "metrics", "train"]
+    what = sys.argv[1:] or ["inference", "metrics", "train", "flags"]
+    if "flags" in what:
+        golden_flags()
     if "inference" in what:
         main()
     if "metrics" in what:

@@ -72,6 +72,26 @@ def test_fusion_golden_64_and_odd():
         assert err(out, c["out"]) < TOL, (tag, err(out, c["out"]))
 
 
+def test_fusion_with_improvements_switched_off():
+    """configs/train_config.yaml model.fusion.improvements (io.py:186-193): the HIP fusion built with one improvement off
+    (each of the six) and with all off, against the REFERENCE's outputs for those networks (tests/golden/fusion_flags.pt).
+    The state_dict handed over holds only the keys that network owns, as a checkpoint of it would."""
+    E = mod("engine")
+    g = load_golden("fusion_flags.pt")
+    sd = dict(load_golden("fusion_full.pt")["sd"])
+    sd.update(g["simple"])
+    imgs = {k: E.nchw_to_map(v.float(), DEV) for k, v in g["imgs"].items()}
+    feats = {k: E.nchw_to_map(v.float(), DEV) for k, v in g["feats"].items()}
+    lr = E.nchw_to_map(g["lr"], DEV)
+    outs = []
+    for v in g["variants"]:
+        net = mod("fusion").FusionNet({k: sd[k] for k in v["keys"]}, DEV, flags=v["flags"])
+        out = E.map_to_nchw(net(lr, imgs, feats))
+        assert err(out, v["out"]) < TOL, ([k for k, on in v["flags"].items() if not on], err(out, v["out"]))
+        outs.append(v["out"])
+    assert all((outs[i] - outs[-1]).abs().max() > 1e-3 for i in range(6))      # the variants really are different networks
+
+
 # ------------------------------------------------------------------ oracle at the real dimensions
 def test_full_size_blocks_vs_oracle():
     """One group / stage of every expert at embed 180 (head dims 30/53/122/46/77, d_inner 360, dt_rank 12)."""

@@ -49,6 +49,20 @@ def test_fusion_full_both_sizes():
             _close(a, b)
 
 
+def test_fusion_with_improvements_switched_off():
+    """model.fusion.improvements of configs/train_config.yaml (io.py:186-193): each improvement off alone, and all off --
+    the reference's own outputs for the network it builds then (oracle/make_golden.py golden_flags)"""
+    g = load_golden("fusion_flags.pt")
+    sd = dict(load_golden("fusion_full.pt")["sd"])
+    sd.update(g["simple"])
+    imgs = {k: v.float() for k, v in g["imgs"].items()}
+    feats = {k: v.float() for k, v in g["feats"].items()}
+    assert len(g["variants"]) == 7
+    for v in g["variants"]:
+        have = {k: sd[k] for k in v["keys"]}                    # only what the variant's network owns
+        _close(fusion.fusion_forward(have, g["lr"], imgs, feats, flags=v["flags"]), v["out"])
+
+
 def test_host_logic_40x56():
     h = load_golden("host_40x56.pt")
     w = {n: load_golden(f"{f}_small.pt")["sd"] for n, f in
