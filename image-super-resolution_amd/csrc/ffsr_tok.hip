@@ -31,23 +31,23 @@ namespace {
 
 // The wave's 16 rows, fp32, in operand order: lane (token l & 15, q = l >> 4) holds columns 32 s + 8 q + 4 h + 0..3.
 template <int KS1>
-__device__ __forceinline__ void tok_load_rows(const TokArgs& p, const float* xr, int q, floatx4 (&xv)[KS1][2]) {
+__device__ __forceinline__ void tok_load_rows(const float* xr, int K, int q, floatx4 (&xv)[KS1][2]) {
 #pragma unroll
   for (int s = 0; s < KS1; ++s)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = 32 * s + 8 * q + 4 * h;
-      xv[s][h] = (k < p.K) ? *reinterpret_cast<const floatx4*>(xr + k) : floatx4{0.f, 0.f, 0.f, 0.f};   // K % 4 == 0
+      xv[s][h] = (k < K) ? *reinterpret_cast<const floatx4*>(xr + k) : floatx4{0.f, 0.f, 0.f, 0.f};   // K % 4 == 0
     }
 }
 
 // rows -> (optionally normalised: two-pass LayerNorm statistics over the row, which is spread over the lanes l, l^16, l^32,
 // l^48) bf16 hi / lo B operands of the first GEMM.  xv is left untouched (it may serve as the residual).
 template <int KS1>
-__device__ __forceinline__ void tok_prepare(const TokArgs& p, int q, const floatx4 (&xv)[KS1][2], bf16x8 (&a_hi)[KS1],
+__device__ __forceinline__ void tok_prepare(int K, bool ln, float eps, int q, const floatx4 (&xv)[KS1][2], bf16x8 (&a_hi)[KS1],
                                             bf16x8 (&a_lo)[KS1]) {
   float mean = 0.f, rstd = 1.f;
-  if (p.pre_ln) {
+  if (ln) {
     float s1 = 0.f;
 #pragma unroll
     for (int s = 0; s < KS1; ++s)
@@ -55,13 +55,13 @@ __device__ __forceinline__ void tok_prepare(const TokArgs& p, int q, const float
       for (int h = 0; h < 2; ++h) s1 += (xv[s][h][0] + xv[s][h][1]) + (xv[s][h][2] + xv[s][h][3]);
     s1 += __shfl_xor(s1, 16, 64);
     s1 += __shfl_xor(s1, 32, 64);
-    mean = s1 / (float)p.K;
+    mean = s1 / (float)K;
     float s2 = 0.f;
 #pragma unroll
     for (int s = 0; s < KS1; ++s)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bool in = 32 * s + 8 * q + 4 * h < p.K;
+        const bool in = 32 * s + 8 * q + 4 * h < K;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float d = in ? xv[s][h][c] - mean : 0.f;
@@ -70,14 +70,14 @@ __device__ __forceinline__ void tok_prepare(const TokArgs& p, int q, const float
       }
     s2 += __shfl_xor(s2, 16, 64);
     s2 += __shfl_xor(s2, 32, 64);
-    rstd = rsqrtf(s2 / (float)p.K + p.eps1);
+    rstd = rsqrtf(s2 / (float)K + eps);
   }
 #pragma unroll
   for (int s = 0; s < KS1; ++s) {
     floatx4 v[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const bool in = 32 * s + 8 * q + 4 * h < p.K;
+      const bool in = 32 * s + 8 * q + 4 * h < K;
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[h][c] = in ? (xv[s][h][c] - mean) * rstd : 0.f;
     }
@@ -91,8 +91,10 @@ __device__ __forceinline__ void tok_prepare(const TokArgs& p, int q, const float
 
 // Epilogue of a wave's 16 tokens: accumulator tile n of lane (token, q) holds columns 32 (n >> 1) + 8 q + 4 (n & 1) + 0..3
 // (the packed W2 row order), i.e. the same column groups the lane loaded of its input row.
-template <int NT2>
-__device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT2], long long tok, bool tok_ok, size_t row, int q) {
+// XR2: the residual after the post-LN is the row xr the wave holds (a head's result), not a global read.
+template <int NT2, bool XR2>
+__device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT2], const floatx4 (&xr)[NT2 / 2][2], long long tok,
+                                             bool tok_ok, size_t row, int q) {
   const int N = p.N;
 #pragma unroll
   for (int n = 0; n < NT2; ++n) {
@@ -114,6 +116,7 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
       v = floatx4{0.f, 0.f, 0.f, 0.f};
     }
     acc[n] = v;
+    if (p.out_pre_ln && tok_ok && col < N) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + col) = v;
   }
   if (p.g2) {       // LayerNorm over the N output columns of the token (two-pass), affine, second residual
     float s1 = 0.f;
@@ -141,7 +144,8 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
       const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
       if (col < N) {
         floatx4 v = acc[n] * rstd * *reinterpret_cast<const floatx4*>(p.g2 + col) + *reinterpret_cast<const floatx4*>(p.be2 + col);
-        if (p.res2) v += *reinterpret_cast<const floatx4*>(p.res2 + row * p.ldr2 + col);
+        if constexpr (XR2) v += xr[n >> 1][n & 1];
+        else if (p.res2) v += *reinterpret_cast<const floatx4*>(p.res2 + row * p.ldr2 + col);
         acc[n] = v;
       }
     }
@@ -150,7 +154,7 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
 #pragma unroll
   for (int n = 0; n < NT2; ++n) {
     const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
-    if (p.out && col < N) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + col) = acc[n];
+    if (p.out && !p.out_pre_ln && col < N) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + col) = acc[n];
     if (p.o_hi && col < p.ldp) {      // columns N .. ldp-1 of the planes are written as zeros (acc is zero there)
       unsigned h0, h1, l0, l1;
       split4(acc[n], h0, h1, l0, l1);
@@ -160,18 +164,82 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
   }
 }
 
+// The head's result row (bias already added; tile (s, g) of lane (token, q) = columns 32 s + 8 q + 4 g + 0..3):
+//   hv = LN0?(hv) + hres + hres2 * hvec2[batch];  columns >= K stay zero (they are the k padding of the chain's first GEMM)
+template <int KS1>
+__device__ __forceinline__ void tok_head_epilogue(const TokArgs& p, floatx4 (&hv)[KS1][2], size_t row, int q) {
+  const int N = p.K;
+  if (p.g0) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) s1 += (hv[s][h][0] + hv[s][h][1]) + (hv[s][h][2] + hv[s][h][3]);   // padding columns are exact zeros
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 / (float)N;
+    float s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool in = 32 * s + 8 * q + 4 * h < N;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = in ? hv[s][h][c] - mean : 0.f;
+          hv[s][h][c] = d;
+          s2 = fmaf(d, d, s2);
+        }
+      }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 / (float)N + p.eps0);
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = 32 * s + 8 * q + 4 * h;
+        if (col < N)
+          hv[s][h] = hv[s][h] * rstd * *reinterpret_cast<const floatx4*>(p.g0 + col) + *reinterpret_cast<const floatx4*>(p.be0 + col);
+      }
+  }
+  const float* v2 = p.hvec2 ? p.hvec2 + (row / (size_t)p.rows_per_batch) * N : nullptr;
+#pragma unroll
+  for (int s = 0; s < KS1; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = 32 * s + 8 * q + 4 * h;
+      if (col < N) {
+        if (p.hres) hv[s][h] += *reinterpret_cast<const floatx4*>(p.hres + row * p.ldhr + col);
+        if (p.hres2) {
+          floatx4 r = *reinterpret_cast<const floatx4*>(p.hres2 + row * p.ldhr2 + col);
+          if (v2) r *= *reinterpret_cast<const floatx4*>(v2 + col);
+          hv[s][h] += r;
+        }
+      }
+    }
+}
+
 // MODE 0: hidden = GELU(W1 x + b1)            (G = 2 tiles of 16 hidden features per 32-deep step of the second GEMM)
 // MODE 1: hidden = (W1a x + b1a) * (W1b x + b1b)   (SimpleGate; G = 4: tiles 0,1 = first halves, 2,3 = second halves)
 // MODE 2: no second GEMM: out = act(W1 pre(x) + b1) * cvec * cscale, 32 output features per step, stored per step (the rows of
 //         W1 are packed in the lane-column order, so a lane stores 8 consecutive columns per step); NT2 is unused (2)
+// MODE 3: the HEAD alone (below) followed by the chain's epilogue; NT2 = 2 KS1.
 // RX: the residual is the input row itself (accumulators start from it; requires K == N, NT2 == 2 KS1)
 // TERMS 1 (plain-bf16 mode): one MFMA per product on the hi halves of the fragments.
-template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int TERMS>
+// KS0 > 0: HEAD -- a linear layer (KS0 k steps of 32 -> the chain's K columns) in front of the chain, see TokArgs; the loaded
+// rows are the head's input, the chain runs on the head's result row, which never leaves the registers.
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int TERMS, int KS0>
 __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
+  constexpr bool HEAD = KS0 > 0;
+  constexpr int KSL = HEAD ? KS0 : KS1;            // k steps of the rows loaded from HBM
   constexpr int G = MODE == 1 ? 4 : 2;
-  constexpr int F1 = G * KS1 * 2;                  // 1 KB pieces of a W1 fill
-  constexpr int F2 = MODE == 2 ? 0 : NT2 * 2;      // ... of a W2 fill
-  constexpr int FMAX = F1 > F2 ? F1 : F2;
+  constexpr int F0 = HEAD ? 2 * KS0 * 2 : 0;       // 1 KB pieces of a head fill (two 16-feature tiles x KS0 k steps x hi / lo)
+  constexpr int F1 = MODE == 3 ? 0 : G * KS1 * 2;  // ... of a W1 fill
+  constexpr int F2 = MODE >= 2 ? 0 : NT2 * 2;      // ... of a W2 fill
+  constexpr int F12 = F1 > F2 ? F1 : F2;
+  constexpr int FMAX = F0 > F12 ? F0 : F12;
+  static_assert(MODE != 3 || (HEAD && NT2 == 2 * KS1), "MODE 3 is the head alone");
   constexpr int SLOT = FMAX * 1024;
   constexpr int PPW = (FMAX + WAVES - 1) / WAVES;  // LDS-DMA instructions per wave and fill (padded with dummy pieces)
   static_assert(!RX || NT2 == 2 * KS1, "residual-from-input needs the same column groups on both sides");
@@ -182,7 +250,8 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4;
-  const int nfill = (MODE == 2 ? p.steps : 2 * p.steps) + p.tsteps;     // + the fills of the optional tail GEMM
+  const int hsteps = HEAD ? KS1 : 0;                                    // head fills come first in a tile's fill sequence
+  const int nfill = hsteps + (MODE == 2 ? p.steps : MODE == 3 ? 0 : 2 * p.steps) + p.tsteps;   // + the optional tail GEMM's
   const int ntile = (p.M + 16 * WAVES - 1) / (16 * WAVES);
   const int my_tiles = (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles blockIdx.x, + gridDim.x, ...
   const int total_fills = my_tiles * nfill;
@@ -193,13 +262,16 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   auto issue_fill = [&](int fg) {
 #if !(FFSR_TOK_ABL & 8)
     const bool live = fg < total_fills;
-    const int f = fg % nfill;
-    const int nmain = nfill - p.tsteps;
-    const bool tail = f >= nmain;                    // (tail fills have the W1 shape of 2 tiles: F3 = 2 KS1 2 pieces)
-    const bool second = MODE != 2 && !tail && (f & 1);
+    const int ft = fg % nfill;
+    const bool head = HEAD && ft < hsteps;
+    const int f = ft - hsteps;                       // index within the chain's own fills
+    const int nmain = nfill - hsteps - p.tsteps;
+    const bool tail = !head && f >= nmain;           // (tail fills have the W1 shape of 2 tiles: F3 = 2 KS1 2 pieces)
+    const bool second = MODE != 2 && !head && !tail && (f & 1);
     constexpr int F3 = 2 * KS1 * 2;
-    const int npiece = tail ? F3 : (second ? F2 : F1);
-    const unsigned char* src0 = tail ? p.w3 + (size_t)(f - nmain) * (F3 * 1024)
+    const int npiece = head ? F0 : tail ? F3 : (second ? F2 : F1);
+    const unsigned char* src0 = head ? p.w0 + (size_t)ft * (F0 * 1024)
+                              : tail ? p.w3 + (size_t)(f - nmain) * (F3 * 1024)
                               : MODE == 2 ? p.w1 + (size_t)f * (F1 * 1024)
                               : (second ? p.w2 + (size_t)(f >> 1) * (F2 * 1024) : p.w1 + (size_t)(f >> 1) * (F1 * 1024));
     unsigned char* slot = smem + (fg % D) * SLOT;
@@ -222,6 +294,9 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   for (int i = threadIdx.x; i < p.steps * G * 16; i += WAVES * 64) b1s[i] = p.b1[i];
   float* const b3s = b1s + p.steps * G * 16;
   for (int i = threadIdx.x; i < p.tsteps * 32; i += WAVES * 64) b3s[i] = p.b3[i];
+  float* const b0s = b3s + p.tsteps * 32;
+  for (int i = threadIdx.x; i < hsteps * 32; i += WAVES * 64) b0s[i] = p.b0[i];
+  const int KL = HEAD ? p.K0 : p.K;                 // channels of the loaded rows
 
   auto tile_row = [&](int tile, long long& tok, bool& ok) -> size_t {
     tok = ((long long)tile * WAVES + wave) * 16 + (lane & 15);
@@ -229,11 +304,11 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
     return (size_t)(ok ? tok : p.M - 1);
   };
 
-  floatx4 xv[KS1][2];      // the rows of the tile about to be computed (fp32)
+  floatx4 xv[KSL][2];      // the rows of the tile about to be computed (fp32)
   {
     long long t_;
     bool o_;
-    tok_load_rows<KS1>(p, p.x + tile_row(blockIdx.x, t_, o_) * p.ldx, q, xv);
+    tok_load_rows<KSL>(p.x + tile_row(blockIdx.x, t_, o_) * p.ldx, KL, q, xv);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bias stores (before the first barrier)
 
@@ -243,12 +318,14 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
     bool tok_ok;
     const size_t row = tile_row(tile, tok, tok_ok);
     bf16x8 a_hi[KS1], a_lo[KS1];
-    tok_prepare<KS1>(p, q, xv, a_hi, a_lo);
-    floatx4 acc[NT2];
+    floatx4 hv[KS1][2];     // the chain's input row: the loaded row, or the head's result
+    if constexpr (!HEAD) {
+      tok_prepare<KS1>(p.K, p.pre_ln != 0, p.eps1, q, xv, a_hi, a_lo);
 #pragma unroll
-    for (int n = 0; n < NT2; ++n) {
-      if constexpr (RX) acc[n] = xv[n >> 1][n & 1];       // x + ...: the residual is the row we already hold
-      else acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < KS1; ++s) {
+        hv[s][0] = xv[s][0];
+        hv[s][1] = xv[s][1];
+      }
     }
     // PFETCH: the next tile's rows start their way from HBM now and are first touched after this tile's epilogue (48 .. 80
     // registers in flight; the wide shapes, which would spill, fetch them after the epilogue instead)
@@ -258,9 +335,63 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       const int nt = min(tile + (int)gridDim.x, ntile - 1);
       long long t_;
       bool o_;
-      tok_load_rows<KS1>(p, p.x + tile_row(nt, t_, o_) * p.ldx, q, xv);
+      tok_load_rows<KSL>(p.x + tile_row(nt, t_, o_) * p.ldx, KL, q, xv);
     };
-    if constexpr (PFETCH) fetch_next();
+    if constexpr (!HEAD && PFETCH) fetch_next();
+
+    if constexpr (HEAD) {
+      // ---- head GEMM: 32 output features per step (two tiles over all KS0 k steps), results in the chain's operand order
+      {
+        bf16x8 i_hi[KS0], i_lo[KS0];
+        tok_prepare<KS0>(p.K0, false, 0.f, q, xv, i_hi, i_lo);
+        if constexpr (PFETCH) fetch_next();
+#pragma unroll
+        for (int hs = 0; hs < KS1; ++hs) {
+#if !(FFSR_TOK_ABL & 4)
+          wait_vm<(D - 2) * PPW>();
+          __builtin_amdgcn_s_barrier();
+#endif
+          issue_fill(fbase + hs + D - 1);
+          const unsigned char* S0 = smem + ((fbase + hs) % D) * SLOT + lane * 16;
+          floatx4 hx[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int s = 0; s < KS0; ++s) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const bf16x8 wh = *reinterpret_cast<const bf16x8*>(S0 + ((g * KS0 + s) * 2 + 0) * 1024);
+              const bf16x8 wl = *reinterpret_cast<const bf16x8*>(S0 + ((g * KS0 + s) * 2 + 1) * 1024);
+              if constexpr (TERMS == 3) {
+                hx[g] = mfma16(wh, i_lo[s], hx[g]);
+                hx[g] = mfma16(wl, i_hi[s], hx[g]);
+              }
+              hx[g] = mfma16(wh, i_hi[s], hx[g]);
+            }
+          }
+          const float* bs = b0s + hs * 32 + 4 * q;
+          hv[hs][0] = hx[0] + *reinterpret_cast<const floatx4*>(bs);          // (zero-padded rows / bias: columns >= K are 0)
+          hv[hs][1] = hx[1] + *reinterpret_cast<const floatx4*>(bs + 16);
+        }
+      }
+      if constexpr (MODE != 3) {
+        tok_head_epilogue<KS1>(p, hv, row, q);
+        tok_prepare<KS1>(p.K, p.pre_ln != 0, p.eps1, q, hv, a_hi, a_lo);
+      }
+    }
+    if constexpr (MODE == 3) {
+      floatx4 acc[NT2];
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) acc[n] = hv[n >> 1][n & 1];
+      tok_epilogue<NT2, false>(p, acc, hv, tok, tok_ok, row, q);
+      if constexpr (!PFETCH) fetch_next();
+      continue;
+    }
+    floatx4 acc[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      if constexpr (RX) acc[n] = hv[n >> 1][n & 1];       // x + ...: the residual is the row we already hold
+      else acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int fb = fbase + hsteps;      // this tile's first chain fill
 
     if constexpr (MODE == 2) {
       for (int st = 0; st < p.steps; ++st) {
@@ -268,8 +399,8 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
         wait_vm<(D - 2) * PPW>();      // (the stores of the last steps are younger than the fill waited for: conservative)
         __builtin_amdgcn_s_barrier();
 #endif
-        issue_fill(fbase + st + D - 1);
-        const unsigned char* S1 = smem + ((fbase + st) % D) * SLOT + lane * 16;
+        issue_fill(fb + st + D - 1);
+        const unsigned char* S1 = smem + ((fb + st) % D) * SLOT + lane * 16;
         floatx4 hx[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < KS1; ++s) {
@@ -324,8 +455,8 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       wait_vm<(D - 2) * PPW>();
       __builtin_amdgcn_s_barrier();
 #endif
-      issue_fill(fbase + 2 * st + D - 1);
-      const unsigned char* S1 = smem + ((fbase + 2 * st) % D) * SLOT + lane * 16;
+      issue_fill(fb + 2 * st + D - 1);
+      const unsigned char* S1 = smem + ((fb + 2 * st) % D) * SLOT + lane * 16;
       floatx4 hx[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) hx[g] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -373,8 +504,8 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       wait_vm<(D - 2) * PPW>();
       __builtin_amdgcn_s_barrier();
 #endif
-      issue_fill(fbase + 2 * st + D);
-      const unsigned char* S2 = smem + ((fbase + 2 * st + 1) % D) * SLOT + lane * 16;
+      issue_fill(fb + 2 * st + D);
+      const unsigned char* S2 = smem + ((fb + 2 * st + 1) % D) * SLOT + lane * 16;
 #pragma unroll
       for (int n = 0; n < NT2; ++n) {
 #if FFSR_TOK_ABL & 2
@@ -391,7 +522,11 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
         acc[n] = mfma16(wh, h_hi, acc[n]);
       }
     }
-    tok_epilogue<NT2>(p, acc, tok, tok_ok, row, q);
+    if constexpr (NT2 == 2 * KS1) tok_epilogue<NT2, HEAD && !RX>(p, acc, hv, tok, tok_ok, row, q);
+    else {
+      floatx4 none[NT2 / 2][2];
+      tok_epilogue<NT2, false>(p, acc, none, tok, tok_ok, row, q);
+    }
     if constexpr (MODE != 2 && NT2 == 2 * KS1) {
       if (p.tsteps) {
         // ---- tail: the chain's output row (acc, already in operand order: tile pair (2 s, 2 s + 1) = k step s) feeds one more GEMM
@@ -449,15 +584,16 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
   wait_vm<0>();     // the dummy pieces of the last fills
 }
 
-template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int TERMS>
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int TERMS, int KS0>
 int launch_tok4(const TokArgs& a, hipStream_t st) {
   constexpr int G = MODE == 1 ? 4 : 2;
-  constexpr int F1 = G * KS1 * 2, F2 = MODE == 2 ? 0 : NT2 * 2, FMAX = F1 > F2 ? F1 : F2;
-  const int lds = D * FMAX * 1024 + WAVES * 1024 + a.steps * G * 16 * 4 + a.tsteps * 32 * 4;
+  constexpr int F0 = 4 * KS0, F1 = MODE == 3 ? 0 : G * KS1 * 2, F2 = MODE >= 2 ? 0 : NT2 * 2;
+  constexpr int F12 = F1 > F2 ? F1 : F2, FMAX = F0 > F12 ? F0 : F12;
+  const int lds = D * FMAX * 1024 + WAVES * 1024 + a.steps * G * 16 * 4 + a.tsteps * 32 * 4 + (KS0 > 0 ? KS1 * 32 * 4 : 0);
   if (lds > 160 * 1024) return FFSR_EINVAL;
   static unsigned long long attr_set = 0;
   static int num_cu = 0;
-  const void* fn = reinterpret_cast<const void*>(&tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH, TERMS>);
+  const void* fn = reinterpret_cast<const void*>(&tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH, TERMS, KS0>);
   if (ffsr_allow_dynamic_lds(&fn, 1, 160 * 1024, &attr_set) != FFSR_OK) return FFSR_ELAUNCH;
   if (!num_cu) {
     int dev = 0;
@@ -469,27 +605,28 @@ int launch_tok4(const TokArgs& a, hipStream_t st) {
   const int ntile = (a.M + per - 1) / per;
   const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;     // small rings (NAFNet widths): two workgroups share a CU
   const int grid = ntile < num_cu * wg_per_cu ? ntile : num_cu * wg_per_cu;
-  FFSR_LAUNCH((tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH, TERMS>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+  FFSR_LAUNCH((tok_chain_kernel<KS1, NT2, WAVES, D, MODE, RX, PFETCH, TERMS, KS0>), dim3(grid), dim3(WAVES * 64), lds, st, a);
   return ffsr_launch_status();
 }
 
-template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH>
+template <int KS1, int NT2, int WAVES, int D, int MODE, bool RX, bool PFETCH, int KS0>
 int launch_tok(const TokArgs& a, hipStream_t st) {
-  return g_ffsr_gemm_terms == 1 ? launch_tok4<KS1, NT2, WAVES, D, MODE, RX, PFETCH, 1>(a, st)
-                                : launch_tok4<KS1, NT2, WAVES, D, MODE, RX, PFETCH, 3>(a, st);
+  return g_ffsr_gemm_terms == 1 ? launch_tok4<KS1, NT2, WAVES, D, MODE, RX, PFETCH, 1, KS0>(a, st)
+                                : launch_tok4<KS1, NT2, WAVES, D, MODE, RX, PFETCH, 3, KS0>(a, st);
 }
 
-template <int KS1, int NT2, int MODE, bool RX>
+template <int KS1, int NT2, int MODE, bool RX, int KS0 = 0>
 int launch_tok_w(const TokArgs& a, int waves, hipStream_t st) {
   constexpr int G = MODE == 1 ? 4 : 2;
-  constexpr int FMAX = (MODE == 2 || G * KS1 * 2 > NT2 * 2) ? G * KS1 * 2 : NT2 * 2;
-  // ring depth: 4 slots while they fit in ~128 KB; the single-GEMM mode (one fill per short step, stores in the loop) 5
-  constexpr int D = MODE == 2 ? (FMAX * 5 <= 140 ? 5 : (FMAX * 4 <= 148 ? 4 : 3)) : (FMAX * 4 <= 128 ? 4 : 3);
+  constexpr int F0 = 4 * KS0, F1 = MODE == 3 ? 0 : G * KS1 * 2, F2 = MODE >= 2 ? 0 : NT2 * 2;
+  constexpr int F12 = F1 > F2 ? F1 : F2, FMAX = F0 > F12 ? F0 : F12;
+  // ring depth: 4 slots while they fit in ~128 KB; the single-GEMM modes (one fill per short step, stores in the loop) 5
+  constexpr int D = (MODE == 2 || MODE == 3) ? (FMAX * 5 <= 140 ? 5 : (FMAX * 4 <= 148 ? 4 : 3)) : (FMAX * 4 <= 128 ? 4 : 3);
   // the next tile's rows are prefetched into registers where that fits the 256 registers of two waves per SIMD
-  constexpr bool PF8 = MODE == 2 || KS1 <= 8;
+  constexpr bool PF8 = KS0 > 0 ? (RX && KS0 <= 6 && KS1 <= 6) : (MODE == 2 || KS1 <= 8);
   switch (waves) {
-    case 4: return launch_tok<KS1, NT2, 4, D, MODE, RX, true>(a, st);
-    case 8: return launch_tok<KS1, NT2, 8, D, MODE, RX, PF8>(a, st);
+    case 4: return launch_tok<KS1, NT2, 4, D, MODE, RX, true, KS0>(a, st);
+    case 8: return launch_tok<KS1, NT2, 8, D, MODE, RX, PF8, KS0>(a, st);
     default: return FFSR_EINVAL;
   }
 }
@@ -497,14 +634,36 @@ int launch_tok_w(const TokArgs& a, int waves, hipStream_t st) {
 }  // namespace
 
 namespace {
+struct TokHead {
+  const void* w0;
+  const float* b0;
+  const float* g0;
+  const float* be0;
+  float eps0;
+  const float* hres;
+  int ldhr;
+  const float* hres2;
+  int ldhr2;
+  const float* hvec2;
+  int rows_per_batch;
+};
+
 int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
                      const float* cvec, const float* res, int ldr, const float* rvec, const float* g2, const float* be2,
                      const float* res2, int ldr2, float* out, int ldo, void* out_hi, void* out_lo, int ldp, long long M, int K,
                      int N, int steps, int mode, int pre_ln, float eps1, float eps2, float cscale, float rscale, int waves,
                      const void* w3, const float* b3, const float* res3, int ldr3, float* out3, int ldo3, int N3, int act3,
-                     float slope3, float cscale3, float rscale3, void* stream) {
+                     float slope3, float cscale3, float rscale3, void* stream, const TokHead* hd = nullptr) {
   const bool tail = w3 != nullptr;
   FFSR_CHECK(x && w1 && b1 && w2 && (out || (out_hi && out_lo) || tail) && M > 0 && M < (1ll << 31));
+  if (hd) {       // the loaded rows are the head's input (K0 = K channels); the chain's own input never exists in memory
+    FFSR_CHECK(hd->w0 && hd->b0 && ((uintptr_t)hd->w0 & 15) == 0 && mode == 0 && K == N && !res && !res2 && !cvec && !rvec);
+    FFSR_CHECK(!hd->g0 || (hd->be0 && ((uintptr_t)hd->g0 & 15) == 0 && ((uintptr_t)hd->be0 & 15) == 0));
+    FFSR_CHECK(!hd->hres || (hd->ldhr >= K && (hd->ldhr & 3) == 0 && ((uintptr_t)hd->hres & 15) == 0));
+    FFSR_CHECK(!hd->hres2 || (hd->ldhr2 >= K && (hd->ldhr2 & 3) == 0 && ((uintptr_t)hd->hres2 & 15) == 0));
+    FFSR_CHECK(!hd->hvec2 || (hd->hres2 && hd->rows_per_batch > 0 && ((uintptr_t)hd->hvec2 & 15) == 0));
+    FFSR_CHECK(cscale == 1.0f && rscale == 1.0f);
+  }
   FFSR_CHECK(K > 0 && N > 0 && steps > 0 && (K & 3) == 0 && (N & 3) == 0 && ldx >= K && (ldx & 3) == 0);
   FFSR_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)b1 & 3) == 0);
   FFSR_CHECK(!out || (ldo >= N && (ldo & 3) == 0 && ((uintptr_t)out & 15) == 0));
@@ -535,6 +694,23 @@ int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, c
   a.res_is_x = (res == x && ldr == ldx && K == N && !cvec && !rvec && cscale == 1.0f && rscale == 1.0f && nt2 == 2 * ks1) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (waves == 0) waves = 8;
+  if (hd) {
+    a.w0 = (const unsigned char*)hd->w0; a.b0 = hd->b0; a.g0 = hd->g0; a.be0 = hd->be0; a.hres = hd->hres; a.hres2 = hd->hres2;
+    a.hvec2 = hd->hvec2; a.K0 = K; a.ldhr = hd->ldhr; a.ldhr2 = hd->ldhr2; a.rows_per_batch = hd->rows_per_batch;
+    a.hsteps = ks1; a.eps0 = hd->eps0;
+    // without a post-LN the chain is x1 + mlp(norm(x1)) (RX: accumulators start from x1); with one it is norm(mlp(x1)) + x1
+    a.res_is_x = g2 ? 0 : 1;
+    if (!a.res_is_x) return (ks1 == 6 && nt2 == 12) ? launch_tok_w<6, 12, 0, false, 6>(a, waves, st) : FFSR_EINVAL;   // GRL: C = 180
+#define FFSR_TOK_HEAD_CASE(KS, NT) \
+  if (ks1 == KS && nt2 == NT) return launch_tok_w<KS, NT, 0, true, KS>(a, waves, st)
+    FFSR_TOK_HEAD_CASE(6, 12);
+    FFSR_TOK_HEAD_CASE(7, 14);
+    FFSR_TOK_HEAD_CASE(8, 16);
+    FFSR_TOK_HEAD_CASE(9, 18);
+    FFSR_TOK_HEAD_CASE(10, 20);
+#undef FFSR_TOK_HEAD_CASE
+    return FFSR_EINVAL;
+  }
 #define FFSR_TOK_CASE(KS, NT, MD)                                                       \
   if (ks1 == KS && nt2 == NT && mode == MD)                                             \
     return a.res_is_x ? launch_tok_w<KS, NT, MD, true>(a, waves, st) : launch_tok_w<KS, NT, MD, false>(a, waves, st)
@@ -604,4 +780,19 @@ extern "C" int ffsr_tok_gemm_f32(const float* x, int ldx, const void* w1, const 
     case 10: return launch_tok_w<10, 2, 2, false>(a, waves, st);
     default: return FFSR_EINVAL;
   }
+}
+
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_tok_head_chain_f32(const float* a, int lda, const void* w0, const float* b0, const float* g0, const float* be0,
+                                       float eps0, const float* hres, int ldhr, const float* hres2, int ldhr2, const float* hvec2,
+                                       int rows_per_batch, const void* w1, const float* b1, const void* w2, const float* b2,
+                                       const float* g2, const float* be2, float eps2, float* out, int ldo, void* out_hi,
+                                       void* out_lo, int ldp, long long M, int K, int steps, int pre_ln, float eps1,
+                                       const void* w3, const float* b3, const float* res3, int ldr3, float* out3, int ldo3,
+                                       int N3, int act3, float slope3, float cscale3, float rscale3, int waves, void* stream) {
+  FFSR_CHECK(w0 && b0);
+  const TokHead hd = {w0, b0, g0, be0, eps0, hres, ldhr, hres2, ldhr2, hvec2, rows_per_batch};
+  return tok_chain_common(a, lda, w1, b1, w2, b2, nullptr, nullptr, 0, nullptr, g2, be2, nullptr, 0, out, ldo, out_hi, out_lo, ldp, M,
+                          K, K, steps, 0, pre_ln, eps1, eps2, 1.f, 1.f, waves, w3, b3, res3, ldr3, out3, ldo3, N3, act3, slope3,
+                          cscale3, rscale3, stream, &hd);
 }

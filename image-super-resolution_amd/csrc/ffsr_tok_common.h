@@ -40,6 +40,22 @@ struct TokArgs {
   float* out3;               // [M, ldo3]
   int ldr3, ldo3, N3, tsteps, act3;
   float slope3, cscale3, rscale3;
+  // optional HEAD (template KS0 > 0): a linear layer K0 -> K in FRONT of the chain; x then holds the head's input rows
+  // [M, ldx] with K0 channels and the chain's input row is produced in registers:
+  //   x1 = LN0?(W0 x + b0) + hres + hres2 * hvec2[row / rows_per_batch]
+  // (Swin: x1 = x + proj(attn); GRL: x1 = x + norm1(proj(attn)) + conv_branch * channel_attention).  In the chain, the
+  // residual / second residual of x1 come from the registers (RX: out = x1 + mlp(..); otherwise post-LN + x1).
+  // MODE 3 = the head alone with the chain's epilogue (bias-free: b0 rides in the head): out = (W0 x + b0) * cvec * cscale
+  // + res * rvec * rscale [+ post-LN -> planes; out_pre_ln: the fp32 output is the value BEFORE the post-LN].
+  const unsigned char* w0;   // fragment-major [K / 32 steps][2][KS0][2][64][8] (pack_tok_gemm layout)
+  const float* b0;           // [hsteps * 32]
+  const float* g0;           // [K] LayerNorm of the head's output row, or null
+  const float* be0;
+  const float* hres;         // [M, ldhr] or null
+  const float* hres2;        // [M, ldhr2] or null
+  const float* hvec2;        // [batches, K] or null (1)
+  int K0, ldhr, ldhr2, rows_per_batch, hsteps, out_pre_ln;
+  float eps0;
 };
 
 template <int N>

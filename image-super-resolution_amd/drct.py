@@ -35,6 +35,10 @@ class _Swin:
         self.mlp = ops.pack_tok_chain(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "mlp.fc2.weight"],
                                       sd[p + "mlp.fc2.bias"], device, mode=0, ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"])) \
             if ops.tok_chain_ok(dim, dim, 0) else None
+        # ... and the attention's output projection + residual in front of it (drct_arch.py:400-404): x1 = x + proj(attn) only
+        # ever exists in the kernel's registers
+        self.proj_t = ops.pack_tok_gemm(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], device) \
+            if self.mlp is not None and ops.tok_gemm_ok(dim, dim) else None
 
     def __call__(self, x, B, H, W, tail=None):
         """x [P, dim] (row stride may be wider) -> [P, dim]; tail (see ops.tok_chain): the dense block's adjust convolution rides
@@ -46,6 +50,11 @@ class _Swin:
             n = ops.layernorm(x, *self.n1, out_planes=True, want_f32=False) if pl else ops.layernorm(x, *self.n1)
             qkv = ops.linear(n, self.qkv)
         a = ops.window_attn(qkv, self.bias, B, H, W, self.dim, self.heads, self.ws, self.shift, self.scale)
+        if self.proj_t is not None and ops.tok_enabled() and ops.HEAD_FUSED:
+            if tail is not None:
+                ops.tok_head_chain(a, self.proj_t, self.mlp, hres=x, tail=tail, want_f32=False)
+                return None
+            return ops.tok_head_chain(a, self.proj_t, self.mlp, hres=x)
         y = ops.linear(a, self.proj, res=x)
         if self.mlp is not None and ops.tok_enabled():
             if tail is not None:

@@ -71,6 +71,10 @@ class _Block:
         # y + norm2(mlp(y)) as ONE kernel (fc1, GELU, fc2, LayerNorm of the output row, residual; fp32 + planes out)
         self.mlp = ops.pack_tok_chain(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "mlp.fc2.weight"],
                                       sd[p + "mlp.fc2.bias"], device, mode=0) if ops.tok_chain_ok(dim, dim, 0) else None
+        # ... with the attention's output projection, norm1 and the two residuals as its head (x + norm1(proj(attn)) + CAB(x) stays
+        # in the kernel's registers): mixed_attn_block_efficient.py:536-554
+        self.proj_t = ops.pack_tok_gemm(sd[a + "proj.weight"], sd[a + "proj.bias"], device) \
+            if self.mlp is not None and ops.tok_gemm_ok(dim, dim) else None
 
     def __call__(self, x, B, H, W, xp=None):
         """x [P, dim] contiguous tokens (xp: the same tensor as bf16 hi/lo planes, if the producer emitted them)
@@ -83,8 +87,11 @@ class _Block:
         cat = torch.empty(x.shape[0], C, device=x.device)
         ops.grl_window_attn(qkv, 0, self.bw, self.lw, cat, 0, B, H, W, heads, hd, self.shift)
         ops.grl_stripe_attn(qkv, 3 * C // 2, anchor, self.b1, self.b2, self.l1, self.l2, cat, C // 2, B, H, W, heads, hd)
-        a = ops.linear(cat, self.proj)
         c2, att = self.cab(xp.reshape_map(B, H, W) if (pl and xp is not None) else xm)
+        if pl and self.proj_t is not None and ops.tok_enabled() and ops.HEAD_FUSED:
+            return ops.tok_head_chain(cat, self.proj_t, self.mlp, head_ln=self.n1, hres=x, hres2=tokens(c2), hvec2=att,
+                                      rows_per_batch=H * W, post_ln=self.n2, out_planes=True)
+        a = ops.linear(cat, self.proj)
         # y = x + LN(attn(x)) + CAB(x): the channel-attention scaling of CAB (c2 * att[batch]) rides in the LN kernel
         if not pl:
             y = ops.layernorm(a, *self.n1, res1=x, res2=tokens(c2), res2_vec=att, rows_per_batch=H * W)

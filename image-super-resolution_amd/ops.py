@@ -579,6 +579,9 @@ TOK_WAVES = int(os.environ.get("FFSR_TOK_WAVES", "0"))
 TOK_FUSED = os.environ.get("FFSR_TOK", "1") != "0"   # FFSR_TOK=0: LayerNorm / fc1 / fc2 stay separate launches (A/B runs)
 
 
+HEAD_FUSED = os.environ.get("FFSR_TOK_HEAD", "1") != "0"   # FFSR_TOK_HEAD=0: attention proj (+ residual / LayerNorm) as own launches
+
+
 def tok_enabled() -> bool:
     """the fused token chains replace launches of the split-bf16 mode only (the exact f32 mode keeps the f32-MFMA GEMMs)"""
     return TOK_FUSED and GEMM_MODE == "bf16x3"
@@ -642,6 +645,51 @@ def tok_chain(x2d, tc: TokChain, *, res=None, rscale=1.0, rvec=None, cvec=None, 
         Hc = tc.H if tc.mode == 0 else tc.H // 2
         prof.append((e0, e1, 2.0 * M * (tc.K * tc.H + Hc * tc.N), (M, tc.N, tc.K, 1, 3),
                      4.0 * (M * tc.K + tc.H * tc.K + tc.N * Hc + M * tc.N * (1 + (res is not None) + (res2 is not None)))))
+    if out_planes is not None:
+        return (out, out_planes) if out is not None else out_planes
+    return out
+
+
+def tok_head_chain(a2d, head: TokGemm, tc: TokChain, *, head_ln=None, eps0=1e-5, hres=None, hres2=None, hvec2=None,
+                   rows_per_batch=0, post_ln=None, eps2=1e-5, out=None, out_planes=None, want_f32=True, tail=None):
+    """a2d [M, K] -> the chain `tc` applied to x1 = LN0?(head(a)) + hres + hres2 * hvec2[batch], one kernel, x1 never stored
+    (ffsr_tok_head_chain_f32).  post_ln None: y = x1 + mlp(pre(x1)); (gamma, beta): y = LN(mlp(x1)) + x1.
+    Returns like tok_chain (out / planes / tail output)."""
+    assert a2d.dim() == 2 and a2d.stride(1) == 1 and head.K == head.N == tc.K == tc.N and not head.pre_ln and tc.mode == 0
+    M = a2d.shape[0]
+    out3 = None
+    if tail is not None:
+        tg, out3 = tail["tg"], tail["out"]
+        assert tg.K == tc.N and not tg.pre_ln and out3.shape == (M, tg.N) and out3.stride(1) == 1 and out_planes is None
+    if out_planes is True:
+        out_planes = Planes(1, 1, M, tc.N, a2d.device)
+    if out is None and want_f32:
+        out = torch.empty(M, tc.N, device=a2d.device)
+    g0, be0 = head_ln if head_ln is not None else (None, None)
+    g2, be2 = post_ln if post_ln is not None else (None, None)
+    r3 = None if tail is None else tail.get("res")
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    hip.call("ffsr_tok_head_chain_f32", _ptr(a2d), a2d.stride(0), _ptr(head.w1), _ptr(head.b1), _ptr(g0), _ptr(be0), float(eps0),
+             _ptr(hres), 0 if hres is None else hres.stride(0), _ptr(hres2), 0 if hres2 is None else hres2.stride(0), _ptr(hvec2),
+             int(rows_per_batch), _ptr(tc.w1), _ptr(tc.b1), _ptr(tc.w2), _ptr(tc.b2), _ptr(g2), _ptr(be2), float(eps2), _ptr(out),
+             0 if out is None else out.stride(0), None if out_planes is None else _ptr(out_planes.hi),
+             None if out_planes is None else _ptr(out_planes.lo), 0 if out_planes is None else out_planes.Cp, M, tc.K, tc.steps,
+             int(tc.pre_ln), tc.eps1, None if tail is None else _ptr(tail["tg"].w1), None if tail is None else _ptr(tail["tg"].b1),
+             _ptr(r3), 0 if r3 is None else r3.stride(0), _ptr(out3), 0 if out3 is None else out3.stride(0),
+             0 if tail is None else tail["tg"].N, ACT_NONE if tail is None else tail.get("act", ACT_NONE),
+             0.0 if tail is None else float(tail.get("slope", 0.0)), 1.0 if tail is None else float(tail.get("cscale", 1.0)),
+             1.0 if tail is None else float(tail.get("rscale", 1.0)), tok_waves(M, (tc.K + 31) // 32), _stream())
+    if prof is not None:
+        e1.record()
+        n3 = 0 if tail is None else tail["tg"].N
+        prof.append((e0, e1, 2.0 * M * (tc.K * tc.K + tc.K * tc.H + tc.H * tc.N + tc.N * n3), (M, tc.N, tc.K, 1, 3),
+                     4.0 * (M * tc.K * (1 + (hres is not None) + (hres2 is not None)) + tc.K * tc.K + 2 * tc.H * tc.K + n3 * tc.N
+                            + M * n3 * (1 + (r3 is not None)) + (M * tc.N if out is not None else 0))))
+    if tail is not None:
+        return out3 if out is None else (out, out3)
     if out_planes is not None:
         return (out, out_planes) if out is not None else out_planes
     return out

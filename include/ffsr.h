@@ -113,6 +113,23 @@ int ffsr_tok_chain_tail_f32(const float* x, int ldx, const void* w1, const float
                             int pre_ln, float eps1, const void* w3, const float* b3, const float* res3, int ldr3, float* out3,
                             int ldo3, int N3, int act3, float slope3, float cscale3, float rscale3, int waves, void* stream);
 
+/* ffsr_tok_chain_f32 (mode 0) with a HEAD: a K -> K linear layer in front of the chain, inside the same kernel.  The rows read
+ * from HBM are the head's input a [M, lda]; the chain's input row
+ *     x1 = LN0?(W0 a + b0) + hres + hres2 * hvec2[row / rows_per_batch]      (LN0 = LayerNorm(g0, be0, eps0) when g0 != NULL)
+ * exists only in registers.  Without a post-LN (g2 == NULL):  y = x1 + W2 gelu(W1 norm?(x1) + b1) + b2    (Swin block:
+ * x1 = x + proj(attention), drct_arch.py:400-407 -- hres = x); with one:  y = LN2(W2 gelu(W1 x1 + b1) + b2) + x1   (GRL block:
+ * x1 = x + norm1(proj(attention)) + conv_branch * channel_attention, mixed_attn_block_efficient.py:536-554 -- hres = x,
+ * hres2 = the CAB convolution output, hvec2 = its per-image channel-attention scale [batches, K]).  y -> out / planes as in
+ * ffsr_tok_chain_f32; the optional tail (w3 != NULL) as in ffsr_tok_chain_tail_f32.  w0 / b0 in the ffsr_tok_gemm_f32 packing.
+ * Replaces three launches (proj GEMM, residual / LayerNorm kernel, MLP chain) and the two HBM round trips between them. */
+int ffsr_tok_head_chain_f32(const float* a, int lda, const void* w0, const float* b0, const float* g0, const float* be0,
+                            float eps0, const float* hres, int ldhr, const float* hres2, int ldhr2, const float* hvec2,
+                            int rows_per_batch, const void* w1, const float* b1, const void* w2, const float* b2,
+                            const float* g2, const float* be2, float eps2, float* out, int ldo, void* out_hi, void* out_lo,
+                            int ldp, long long M, int K, int steps, int pre_ln, float eps1, const void* w3, const float* b3,
+                            const float* res3, int ldr3, float* out3, int ldo3, int N3, int act3, float slope3, float cscale3,
+                            float rscale3, int waves, void* stream);
+
 /* Token-stationary single GEMM with the producer fused in front: per token row x [K] (fp32, row stride ldx)
  *     out = act( W1 . pre(x) + b1 ) * cvec * cscale       -> fp32 `out` [M, ldo] and / or bf16 hi / lo planes [M, ldp]
  * pre = identity or nn.LayerNorm's normalisation (affine part folded into W1 / b1 by the packer).  Same kernel family as

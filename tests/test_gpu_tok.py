@@ -178,3 +178,69 @@ def test_mlp_with_adjust_tail(K, H, N3, M, act):
         out3 = torch.empty(M, N3, device=DEV)
         ygot, r = ops.tok_chain(xg, tc, res=xg, tail=dict(tg=tg, out=out3, cscale=0.2, res=wg[:, :N3]))
         assert rel(ygot, y) < 3e-5 and rel(r, want3) < 3e-5
+
+
+@pytest.mark.parametrize("K,H,M,waves,tail", [(180, 360, 1000, 8, False), (180, 360, 3000, 4, True), (212, 424, 777, 8, True),
+                                              (244, 488, 2048, 8, False), (276, 276, 1500, 8, True), (308, 308, 4096 + 16, 8, True),
+                                              (180, 360, 352 * 512 + 40, 8, True)])
+def test_swin_block_head_proj_mlp(K, H, M, waves, tail, monkeypatch):
+    """the attention's output projection as the HEAD of the MLP kernel (drct_arch.py:400-407): x1 = x + proj(a);
+    y = x1 + fc2(GELU(fc1(norm2(x1)))) [; adjust tail on y].  x is a channel slice of the dense-concat buffer; x1 is never stored."""
+    ops = mod("ops")
+    monkeypatch.setattr(ops, "TOK_WAVES", waves)
+    g = gen(K + M + 1)
+    wide = torch.randn(M, 308, generator=g) * 1.5 + 0.3
+    x = wide[:, :K]
+    a = torch.randn(M, K, generator=g)
+    w0, b0 = torch.randn(K, K, generator=g) / K ** 0.5, torch.randn(K, generator=g) * 0.1
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    w1, b1 = torch.randn(H, K, generator=g) / K ** 0.5, torch.randn(H, generator=g) * 0.1
+    w2, b2 = torch.randn(K, H, generator=g) / H ** 0.5, torch.randn(K, generator=g) * 0.1
+    w3, b3 = torch.randn(32, K, generator=g) / K ** 0.5, torch.randn(32, generator=g) * 0.1
+    x1 = x.double() + F.linear(a.double(), w0.double(), b0.double())
+    y = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (K,), gamma.double(), beta.double(), 1e-5), w1.double(), b1.double())),
+                      w2.double(), b2.double())
+    head = ops.pack_tok_gemm(w0, b0, DEV)
+    tc = ops.pack_tok_chain(w1, b1, w2, b2, DEV, mode=0, ln=(gamma, beta))
+    wg, ag = wide.to(DEV), a.to(DEV)
+    if not tail:
+        got = ops.tok_head_chain(ag, head, tc, hres=wg[:, :K])
+        assert rel(got, y) < 4e-5
+        return
+    want3 = F.leaky_relu(F.linear(y, w3.double(), b3.double()), 0.2)
+    tg = ops.pack_tok_gemm(w3, b3, DEV)
+    out3 = torch.empty(M, 32, device=DEV)
+    ygot, r = ops.tok_head_chain(ag, head, tc, hres=wg[:, :K], tail=dict(tg=tg, out=out3, act=3, slope=0.2))
+    assert r is out3 and rel(ygot, y) < 4e-5 and rel(out3, want3) < 4e-5
+    only = torch.empty(M, 32, device=DEV)
+    assert ops.tok_head_chain(ag, head, tc, hres=wg[:, :K], tail=dict(tg=tg, out=only, act=3, slope=0.2), want_f32=False) is only
+    assert torch.equal(only, out3)
+
+
+@pytest.mark.parametrize("M,per", [(640, 320), (2 * 1027, 1027), (352 * 512, 352 * 512)])
+def test_grl_block_head_proj_norm_mlp(M, per):
+    """GRL's block tail as one kernel (mixed_attn_block_efficient.py:536-554): y = x + norm1(proj(a)) + c2 * att[image];
+    out = y + norm2(fc2(GELU(fc1(y)))), fp32 and bf16 planes; y is never stored."""
+    ops = mod("ops")
+    K, H = 180, 360
+    g = gen(M)
+    x, a, c2 = (torch.randn(M, K, generator=g) for _ in range(3))
+    att = torch.rand(M // per, K, generator=g)
+    w0, b0 = torch.randn(K, K, generator=g) / K ** 0.5, torch.randn(K, generator=g) * 0.1
+    g0, be0 = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    w1, b1 = torch.randn(H, K, generator=g) / K ** 0.5, torch.randn(H, generator=g) * 0.1
+    w2, b2 = torch.randn(K, H, generator=g) / H ** 0.5, torch.randn(K, generator=g) * 0.1
+    g2, be2 = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    y = x.double() + F.layer_norm(F.linear(a.double(), w0.double(), b0.double()), (K,), g0.double(), be0.double(), 1e-5) \
+        + c2.double() * att.double().repeat_interleave(per, 0)
+    m = F.linear(F.gelu(F.linear(y, w1.double(), b1.double())), w2.double(), b2.double())
+    want = y + F.layer_norm(m, (K,), g2.double(), be2.double(), 1e-5)
+    head = ops.pack_tok_gemm(w0, b0, DEV)
+    tc = ops.pack_tok_chain(w1, b1, w2, b2, DEV, mode=0)
+    d = lambda t: t.to(DEV)
+    got, pl = ops.tok_head_chain(d(a), head, tc, head_ln=(d(g0), d(be0)), hres=d(x), hres2=d(c2), hvec2=d(att), rows_per_batch=per,
+                                 post_ln=(d(g2), d(be2)), out_planes=True)
+    assert rel(got, want) < 4e-5
+    back = pl.buf[0].float() + pl.buf[1].float()
+    assert pl.Cp == 192 and bool((back[:, K:] == 0).all())
+    assert (back[:, :K] - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item()
