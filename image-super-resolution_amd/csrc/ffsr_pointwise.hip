@@ -454,6 +454,121 @@ __global__ __launch_bounds__(256) void dw3x3_run_kernel(const float* __restrict_
   }
 }
 
+// Same operator, register-window form: one wave = a strip of R = 4 image rows x XS columns of 64 channels.  A (R + 2) x 3 input
+// window per lane slides along x: every step fetches ONE new column (R + 2 loads per input half) and emits R output pixels, i.e.
+// 1.5 loads per output instead of the run kernel's 4.5 (its 3 x 6 window serves 4 pixels of one row) -- the run kernel is bound by
+// the L2 -> L1 refill of its window overlap (1063 us for NAFNet's 1408 x 2048 x 128 level, 2.1 TB/s of algorithmic traffic).
+// The columns of the next U = 4 (2 with the gate's two input halves) steps are in flight while the current U are computed.  The 4 waves of a workgroup take 4
+// vertically adjacent strips (their halo rows hit in L1 / the XCD's L2).  Same grid contract as dw3x3_run_kernel.
+template <bool GATE>
+__global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                          float* __restrict__ part, int H, int W, int C, int nchunk, int act,
+                                                          int XS) {
+  __shared__ float red[4][64];
+  constexpr int NH = GATE ? 2 : 1, R = 4, U = GATE ? 2 : 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nxy = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int q8 = nxy >> 3, r8 = nxy & 7, xcd = lin & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int c = (logical % gridDim.x) * 64 + lane;
+  const bool live = c < C;
+  const int cc = live ? c : C - 1;
+  const int chunk = logical / gridDim.x, b = blockIdx.z;
+  const int CW = NH * C;
+  float wt[NH][9], bs[NH];
+#pragma unroll
+  for (int hh = 0; hh < NH; ++hh) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[hh][k] = w[k * CW + hh * C + cc];
+    bs[hh] = bias ? bias[hh * C + cc] : 0.f;
+  }
+  // 32-bit element offsets from the (uniform) base pointers: scalar-base + vector-offset loads, half the address registers
+  // (the launcher takes this kernel only while B * H * W * max(ldi, ldo) < 2^31)
+  const unsigned inb = (unsigned)b * H * W * ldi + cc;
+  const unsigned outb = (unsigned)b * H * W * ldo + c;
+  const int nsy = (H + R - 1) / R, nsx = (W + XS - 1) / XS, nstrip = nsy * nsx;
+  float s = 0.f;
+  for (int sidx = chunk * 4 + wave; sidx < nstrip; sidx += nchunk * 4) {
+    const int sx = sidx / nsy, sy = sidx - sx * nsy;          // vertically adjacent strips are consecutive
+    const int y0 = sy * R, x0 = sx * XS, x1 = min(W, x0 + XS);
+    unsigned rowp[R + 2];
+    float rmask[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+      const int yy = y0 + r - 1;
+      rmask[r] = (yy >= 0 && yy < H) ? 1.f : 0.f;
+      rowp[r] = inb + (unsigned)min(max(yy, 0), H - 1) * W * ldi;
+    }
+    auto load_col = [&](int xx, float (&col)[NH][R + 2]) {      // branch-free: clamped address, value zeroed by the masks
+      const float xm = (xx >= 0 && xx < W) ? 1.f : 0.f;
+      const unsigned xo = (unsigned)min(max(xx, 0), W - 1) * ldi;
+#pragma unroll
+      for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) col[hh][r] = in[rowp[r] + xo + hh * C] * (xm * rmask[r]);
+    };
+    float win[3][NH][R + 2];       // columns x - 1, x, x + 1
+    load_col(x0 - 1, win[0]);
+    load_col(x0, win[1]);
+    auto consume = [&](const float (&buf)[U][NH][R + 2], int xb) {      // buf = columns xb + 1 .. xb + U: outputs at xb .. xb + U - 1
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+          for (int r = 0; r < R + 2; ++r) win[2][hh][r] = buf[u][hh][r];
+        const int x = xb + u;
+        if (x < x1) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            float a[NH];
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+              a[hh] = bs[hh];
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) a[hh] = fmaf(win[kx][hh][r + ky], wt[hh][ky * 3 + kx], a[hh]);
+            }
+            const float g = GATE ? a[0] * a[NH - 1] : ffsr_act(a[0], act, 0.f);
+            if (y0 + r < H) {
+              if (live) out[outb + ((unsigned)(y0 + r) * W + x) * ldo] = g;
+              s += g;
+            }
+          }
+        }
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+          for (int r = 0; r < R + 2; ++r) {
+            win[0][hh][r] = win[1][hh][r];
+            win[1][hh][r] = win[2][hh][r];
+          }
+      }
+    };
+    // two column buffers in alternation: the loads of one are in flight while the other is consumed (past the strip's end the
+    // clamped addresses re-read valid pixels whose values nobody uses)
+    float bufA[U][NH][R + 2], bufB[U][NH][R + 2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_col(x0 + 1 + u, bufA[u]);
+    for (int xb = x0; xb < x1; xb += 2 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_col(xb + U + 1 + u, bufB[u]);
+      consume(bufA, xb);
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_col(xb + 2 * U + 1 + u, bufA[u]);
+      consume(bufB, xb + U);
+    }
+  }
+  if (GATE) {
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && live)
+      part[((size_t)b * nchunk + chunk) * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- resamplers
 // torch F.interpolate(mode='bilinear', align_corners=False, size=(Ho,Wo)): src = (dst+0.5)*in/out - 0.5 clamped at 0
 __device__ __forceinline__ void bilin_coord(int d, float scale, int n, int& i0, int& i1, float& l) {
@@ -631,6 +746,15 @@ __global__ void dihedral_kernel(const float* __restrict__ in, int ldi, float* __
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// strip width of dw3x3_strip_kernel: as long as possible (the 2-column lead-in of a strip is its only overhead) while the launch
+// still has >= ~8 waves per SIMD-slot of the chip to balance (4096 waves)
+inline int dw3x3_strip_width(int H, int W, int cgroups, int B) {
+  const long long rows = (long long)((H + 3) / 4) * cgroups * B;
+  int xs = 512;
+  while (xs > 32 && rows * ((W + xs - 1) / xs) < 4096) xs >>= 1;
+  return xs;
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -755,6 +879,14 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
   if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && pix >= 4096 && B <= 65535) {   // sliding-window kernel
     const long long per_img = (long long)H * W;
     const int nchunk = (int)(per_img / 256 < 1 ? 1 : (per_img / 256 > 8192 ? 8192 : per_img / 256));
+    if (H >= 16 && W >= 64 && pix * (ldi > ldo ? ldi : ldo) < (1ll << 31)) {
+      const int xs = dw3x3_strip_width(H, W, (C + 63) / 64, B);
+      const int ns = ((H + 3) / 4) * ((W + xs - 1) / xs);
+      const int nck = (ns + 3) / 4 > 65535 ? 65535 : (ns + 3) / 4;
+      FFSR_LAUNCH(dw3x3_strip_kernel<false>, dim3((C + 63) / 64, nck, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo,
+                         nullptr, H, W, C, nck, act, xs);
+      return ffsr_launch_status();
+    }
     FFSR_LAUNCH(dw3x3_run_kernel<false>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo,
                        nullptr, H, W, C, nchunk, act);
     return ffsr_launch_status();
@@ -772,8 +904,12 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
 extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
                                         float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream) {
   FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
-  FFSR_LAUNCH(dw3x3_run_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
-                     H, W, C, nchunk, 0);
+  if (H >= 16 && W >= 64 && (long long)B * H * W * (ldi > ldo ? ldi : ldo) < (1ll << 31))     // (any nchunk: a workgroup walks the strips chunk * 4 + wave, + 4 nchunk, ...)
+    FFSR_LAUNCH(dw3x3_strip_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
+                       H, W, C, nchunk, 0, dw3x3_strip_width(H, W, (C + 63) / 64, B));
+  else
+    FFSR_LAUNCH(dw3x3_run_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
+                       H, W, C, nchunk, 0);
   FFSR_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, ST, part, pooled, B, C, nchunk,
                      1.0f / (float)(H * W));
   return ffsr_launch_status();

@@ -220,6 +220,69 @@ __device__ __forceinline__ void tok_head_epilogue(const TokArgs& p, floatx4 (&hv
     }
 }
 
+// MODE 3's input row: the sum of the xdirs partial rows (order of mambair_arch.py:381), LayerNorm with affine, * silu(z).
+template <int KS0>
+__device__ __forceinline__ void tok_gate_prologue(const TokArgs& p, const float* xr, size_t row, int q, floatx4 (&xv)[KS0][2]) {
+  const int K = p.K0;
+  // (compiler barriers between the partial rows: hoisting all 4 x 24 loads of a lane in front of the adds needs ~400 registers
+  //  and spills under the 256 of two waves per SIMD; one row in flight next to the running sum fits)
+  if (p.xdirs == 4) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      asm volatile("" ::: "memory");
+      floatx4 t[KS0][2];
+      tok_load_rows<KS0>(xr + (d == 0 ? 2 : d == 1 ? 1 : 3) * p.xstride, K, q, t);
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) { xv[s][0] += t[s][0]; xv[s][1] += t[s][1]; }
+    }
+    asm volatile("" ::: "memory");
+  }
+  if (p.pg) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) s1 += (xv[s][h][0] + xv[s][h][1]) + (xv[s][h][2] + xv[s][h][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 / (float)K;
+    float s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool in = 32 * s + 8 * q + 4 * h < K;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = in ? xv[s][h][c] - mean : 0.f;
+          xv[s][h][c] = d;
+          s2 = fmaf(d, d, s2);
+        }
+      }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.0f / sqrtf(s2 / (float)K + p.peps);
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = 32 * s + 8 * q + 4 * h;
+        if (col < K)
+          xv[s][h] = xv[s][h] * rstd * *reinterpret_cast<const floatx4*>(p.pg + col) + *reinterpret_cast<const floatx4*>(p.pb + col);
+      }
+  }
+  if (p.z) {
+    floatx4 t[KS0][2];
+    tok_load_rows<KS0>(p.z + row * p.ldz, K, q, t);
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[s][h][c] *= t[s][h][c] / (1.0f + __expf(-t[s][h][c]));
+  }
+}
+
 // MODE 0: hidden = GELU(W1 x + b1)            (G = 2 tiles of 16 hidden features per 32-deep step of the second GEMM)
 // MODE 1: hidden = (W1a x + b1a) * (W1b x + b1b)   (SimpleGate; G = 4: tiles 0,1 = first halves, 2,3 = second halves)
 // MODE 2: no second GEMM: out = act(W1 pre(x) + b1) * cvec * cscale, 32 output features per step, stored per step (the rows of
@@ -343,6 +406,9 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       // ---- head GEMM: 32 output features per step (two tiles over all KS0 k steps), results in the chain's operand order
       {
         bf16x8 i_hi[KS0], i_lo[KS0];
+        if constexpr (MODE == 3) {
+          if (p.xdirs == 4 || p.pg || p.z) tok_gate_prologue<KS0>(p, p.x + row * p.ldx, row, q, xv);
+        }
         tok_prepare<KS0>(p.K0, false, 0.f, q, xv, i_hi, i_lo);
         if constexpr (PFETCH) fetch_next();
 #pragma unroll
@@ -633,6 +699,7 @@ int launch_tok_w(const TokArgs& a, int waves, hipStream_t st) {
 
 }  // namespace
 
+#ifndef FFSR_TOK_ONLY_PROJ   // (analysis builds of the projection kernel alone: hipcc -DFFSR_TOK_ONLY_PROJ -S)
 namespace {
 struct TokHead {
   const void* w0;
@@ -795,4 +862,35 @@ extern "C" int ffsr_tok_head_chain_f32(const float* a, int lda, const void* w0, 
   return tok_chain_common(a, lda, w1, b1, w2, b2, nullptr, nullptr, 0, nullptr, g2, be2, nullptr, 0, out, ldo, out_hi, out_lo, ldp, M,
                           K, K, steps, 0, pre_ln, eps1, eps2, 1.f, 1.f, waves, w3, b3, res3, ldr3, out3, ldo3, N3, act3, slope3,
                           cscale3, rscale3, stream, &hd);
+}
+
+#endif  // FFSR_TOK_ONLY_PROJ
+// See include/ffsr.h for the contract.
+extern "C" int ffsr_tok_proj_f32(const float* x, long long xstride, int xdirs, int ldx, const float* z, int ldz, const float* pg,
+                                 const float* pb, float peps, const void* w0, const float* b0, const float* cvec,
+                                 const float* res, int ldr, const float* rvec, const float* g2, const float* be2, float eps2,
+                                 float* out, int ldo, int out_pre_ln, void* out_hi, void* out_lo, int ldp, long long M, int K,
+                                 int N, float cscale, float rscale, int waves, void* stream) {
+  FFSR_CHECK(x && w0 && b0 && (out || (out_hi && out_lo)) && M > 0 && M < (1ll << 31) && (xdirs == 1 || xdirs == 4));
+  FFSR_CHECK(K > 0 && N > 0 && (K & 3) == 0 && (N & 3) == 0 && ldx >= K && (ldx & 3) == 0 && (xstride & 3) == 0);
+  FFSR_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w0 & 15) == 0 && ((uintptr_t)b0 & 3) == 0);
+  FFSR_CHECK(!z || (ldz >= K && (ldz & 3) == 0 && ((uintptr_t)z & 15) == 0));
+  FFSR_CHECK(!pg || (pb && ((uintptr_t)pg & 15) == 0 && ((uintptr_t)pb & 15) == 0));
+  FFSR_CHECK(!out || (ldo >= N && (ldo & 3) == 0 && ((uintptr_t)out & 15) == 0));
+  FFSR_CHECK(!res || (ldr >= N && (ldr & 3) == 0 && ((uintptr_t)res & 15) == 0));
+  FFSR_CHECK((!cvec || ((uintptr_t)cvec & 15) == 0) && (!rvec || ((uintptr_t)rvec & 15) == 0));
+  FFSR_CHECK(!g2 || (be2 && ((uintptr_t)g2 & 15) == 0 && ((uintptr_t)be2 & 15) == 0));
+  FFSR_CHECK(!out_pre_ln || (out && g2));
+  FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= N && ldp < N + 32 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0));
+  TokArgs a = {};
+  a.x = x; a.xstride = xstride; a.xdirs = xdirs; a.ldx = ldx; a.z = z; a.ldz = ldz; a.pg = pg; a.pb = pb; a.peps = peps;
+  a.w0 = (const unsigned char*)w0; a.b0 = b0; a.w1 = a.w0; a.cvec = cvec; a.res = res; a.ldr = ldr; a.rvec = rvec; a.g2 = g2; a.be2 = be2;
+  a.eps2 = eps2; a.out = out; a.ldo = ldo; a.out_pre_ln = out_pre_ln; a.o_hi = (unsigned short*)out_hi; a.o_lo = (unsigned short*)out_lo;
+  a.ldp = ldp; a.M = (int)M; a.K0 = K; a.K = N; a.N = N; a.cscale = cscale; a.rscale = rscale;
+  const int ks0 = (K + 31) / 32, ks1 = (N + 31) / 32;
+  a.hsteps = ks1;
+  hipStream_t st = (hipStream_t)stream;
+  if (waves == 0) waves = 8;
+  if (ks0 == 12 && ks1 == 6) return launch_tok_w<6, 12, 3, false, 12>(a, waves, st);     // MambaIR out_proj: 360 -> 180
+  return FFSR_EINVAL;
 }

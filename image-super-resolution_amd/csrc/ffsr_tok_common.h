@@ -56,6 +56,14 @@ struct TokArgs {
   const float* hvec2;        // [batches, K] or null (1)
   int K0, ldhr, ldhr2, rows_per_batch, hsteps, out_pre_ln;
   float eps0;
+  // MODE 3 prologue (MambaIR's out_norm + gate in front of out_proj, mambair_arch.py:381-385): the head's input row is
+  //   a = LN(x[0] + x[2 xstride] + x[xstride] + x[3 xstride]; pg, pb, peps) * silu(z)      (xdirs == 4; z != null)
+  const float* z;            // [M, ldz] or null
+  const float* pg;           // [K0] LayerNorm weight or null
+  const float* pb;
+  long long xstride;         // elements between the partial inputs
+  int xdirs, ldz;
+  float peps;
 };
 
 template <int N>

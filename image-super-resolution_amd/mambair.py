@@ -38,6 +38,9 @@ class _VSS:
         self.Ds = dev(sd[s + "Ds"], device)
         self.out_norm = (dev(sd[s + "out_norm.weight"], device), dev(sd[s + "out_norm.bias"], device))
         self.out_proj = ops.pack_conv(sd[s + "out_proj.weight"], None, device)
+        # out_norm + gate + out_proj + skip + ln_2 as one kernel (mambair_arch.py:381-386, :417-419)
+        ow = sd[s + "out_proj.weight"]
+        self.out_proj_t = ops.pack_tok_gemm(ow, None, device, check=False) if ops.tok_proj_ok(ow.shape[1], ow.shape[0]) else None
         self.cab = CAB(sd, p + "conv_blk.", device)
 
     def __call__(self, x, B, H, W):
@@ -53,6 +56,16 @@ class _VSS:
         ut = tokens(u)
         xdbl = ops.linear(ut, self.x_proj)                                    # [P, 4*(R+32)]
         y4 = ops.selective_scan4(ut, xdbl, self.dtw, self.dtb, self.A, self.Ds, B, H, W, Dm, self.R)
+        if pl and self.out_proj_t is not None and ops.tok_enabled() and ops.PROJ_FUSED:
+            # (4-wave workgroups: the 12-k-step rows need ~440 registers, two waves per SIMD would spill)
+            ops_w, ops.TOK_WAVES = ops.TOK_WAVES, ops.TOK_WAVES or 4
+            try:
+                y, n2 = ops.tok_proj(y4[0], self.out_proj_t, xdirs=4, xstride=y4.stride(0), z=xz[:, Dm:], pro_ln=self.out_norm,
+                                     res=x, rvec=self.skip1, post_ln=self.ln2, out_pre_ln=True, out_planes=True)
+            finally:
+                ops.TOK_WAVES = ops_w
+            c2, att = self.cab(n2.reshape_map(B, H, W))
+            return ops.scale_add(y, tokens(c2), avec=self.skip2, bvec=att, rows_per_batch=H * W)
         g = ops.mamba_norm_gate(y4, xz[:, Dm:], *self.out_norm, out_planes=True if pl else None, want_f32=not pl)
         y = ops.linear(g, self.out_proj, res=x, rvec=self.skip1)              # x * skip_scale + out_proj(LN(sum y) * silu(z))
         if pl:

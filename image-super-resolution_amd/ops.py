@@ -524,7 +524,7 @@ def tok_gemm_ok(K: int, N: int) -> bool:
     return K % 4 == 0 and N % 4 == 0 and (K + 31) // 32 in TOK_GEMM_KS
 
 
-def pack_tok_gemm(w, b, device, *, ln=None, eps=1e-5) -> TokGemm:
+def pack_tok_gemm(w, b, device, *, ln=None, eps=1e-5, check=True) -> TokGemm:
     """w [N, K] (+ b [N]) as an nn.Linear / 1x1 nn.Conv2d weight; ln = (gamma, beta) of a LayerNorm(K) in front of it (folded:
     W' = W diag(gamma), b' = b + W beta; the kernel only normalises)."""
     w = w.detach().float().to(device).reshape(w.shape[0], -1)
@@ -534,7 +534,7 @@ def pack_tok_gemm(w, b, device, *, ln=None, eps=1e-5) -> TokGemm:
         gamma, beta = (t.detach().float().to(device).reshape(-1) for t in ln)
         b = b + w @ beta
         w = w * gamma[None, :]
-    assert tok_gemm_ok(K, N), (K, N)
+    assert not check or tok_gemm_ok(K, N), (K, N)
     KS1, steps = (K + 31) // 32, (N + 31) // 32
     wn = torch.zeros(steps * 32, KS1 * 32, device=device)
     bn = torch.zeros(steps * 32, device=device)
@@ -580,6 +580,10 @@ TOK_FUSED = os.environ.get("FFSR_TOK", "1") != "0"   # FFSR_TOK=0: LayerNorm / f
 
 
 HEAD_FUSED = os.environ.get("FFSR_TOK_HEAD", "1") != "0"   # FFSR_TOK_HEAD=0: attention proj (+ residual / LayerNorm) as own launches
+# FFSR_TOK_PROJ=1: MambaIR's out_norm + gate + out_proj + skip + ln_2 as ONE kernel (ffsr_tok_proj_f32).  Off by default: measured
+# 594 us (4-wave workgroups; 991 us with 8) against 591 us for the three launches it replaces -- its tiles are too short (5 us of MFMA
+# work per 64 tokens) to hide the load / store latencies of a workgroup that owns its CU alone (tools/proj_bench.py)
+PROJ_FUSED = os.environ.get("FFSR_TOK_PROJ", "0") == "1"
 
 
 def tok_enabled() -> bool:
@@ -690,6 +694,42 @@ def tok_head_chain(a2d, head: TokGemm, tc: TokChain, *, head_ln=None, eps0=1e-5,
                             + M * n3 * (1 + (r3 is not None)) + (M * tc.N if out is not None else 0))))
     if tail is not None:
         return out3 if out is None else (out, out3)
+    if out_planes is not None:
+        return (out, out_planes) if out is not None else out_planes
+    return out
+
+
+def tok_proj_ok(K: int, N: int) -> bool:
+    return K % 4 == 0 and N % 4 == 0 and (K + 31) // 32 == 12 and (N + 31) // 32 == 6
+
+
+def tok_proj(x2d, tg: TokGemm, *, xdirs=1, xstride=0, z=None, pro_ln=None, peps=1e-5, cvec=None, cscale=1.0, res=None, rvec=None,
+             rscale=1.0, post_ln=None, eps2=1e-5, out_pre_ln=False, out=None, out_planes=None, want_f32=True):
+    """ffsr_tok_proj_f32: y = (W0 a + b0) * cvec * cscale + res * rvec * rscale with a = [sum of xdirs partial rows ->]
+    [LayerNorm(pro_ln) ->] [* silu(z)]; post_ln: planes (and out unless out_pre_ln) receive LayerNorm(y).
+    x2d [M, >= K] is the first partial input; the others lie xstride elements apart."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.shape[1] >= tg.K and not tg.pre_ln
+    M = x2d.shape[0]
+    if out_planes is True:
+        out_planes = Planes(1, 1, M, tg.N, x2d.device)
+    if out is None and (want_f32 or out_planes is None):
+        out = torch.empty(M, tg.N, device=x2d.device)
+    pg, pb = pro_ln if pro_ln is not None else (None, None)
+    g2, be2 = post_ln if post_ln is not None else (None, None)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    hip.call("ffsr_tok_proj_f32", _ptr(x2d), int(xstride), int(xdirs), x2d.stride(0), _ptr(z), 0 if z is None else z.stride(0),
+             _ptr(pg), _ptr(pb), float(peps), _ptr(tg.w1), _ptr(tg.b1), _ptr(cvec), _ptr(res), 0 if res is None else res.stride(0),
+             _ptr(rvec), _ptr(g2), _ptr(be2), float(eps2), _ptr(out), 0 if out is None else out.stride(0), int(out_pre_ln),
+             None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
+             0 if out_planes is None else out_planes.Cp, M, tg.K, tg.N, float(cscale), float(rscale),
+             tok_waves(M, (tg.K + 31) // 32), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * tg.K * tg.N, (M, tg.N, tg.K, 1, 3),
+                     4.0 * (M * tg.K * (xdirs + (z is not None)) + tg.K * tg.N + M * tg.N * (1 + (res is not None)))))
     if out_planes is not None:
         return (out, out_planes) if out is not None else out_planes
     return out

@@ -130,6 +130,22 @@ int ffsr_tok_head_chain_f32(const float* a, int lda, const void* w0, const float
                             const float* res3, int ldr3, float* out3, int ldo3, int N3, int act3, float slope3, float cscale3,
                             float rscale3, int waves, void* stream);
 
+/* Token-stationary projection with a full-row epilogue (and MambaIR's out_norm / gate as its prologue), one kernel:
+ *     a   = x                                                       (xdirs == 1)
+ *         = ((x[0] + x[2 xstride]) + x[xstride]) + x[3 xstride]     (xdirs == 4: the four scan directions, mambair_arch.py:381)
+ *     a   = LN(a; pg, pb, peps)   when pg != NULL;     a *= silu(z)   when z != NULL          (out_norm, y * F.silu(z))
+ *     y   = (W0 a + b0) * cvec * cscale + res * rvec * rscale                                 (out_proj; x * skip_scale + ...)
+ *     g2 != NULL:  n = LN(y; g2, be2, eps2);  planes <- n;  out <- y if out_pre_ln else n      (ln_2 feeding the conv branch)
+ *     g2 == NULL:  out / planes <- y
+ * w0 / b0 in the ffsr_tok_gemm_f32 packing.  Supported: K = 321..384 -> N = 161..192 (MambaIR d_inner 360 -> 180).  Replaces
+ * ffsr_mamba_norm_gate_planes_f32 + the out_proj GEMM + the skip scale_add + the ln_2 LayerNorm of a VSS block
+ * (mambair_arch.py:381-386, :417-419) and the HBM round trips of the gated tensor and of y between them. */
+int ffsr_tok_proj_f32(const float* x, long long xstride, int xdirs, int ldx, const float* z, int ldz, const float* pg,
+                      const float* pb, float peps, const void* w0, const float* b0, const float* cvec, const float* res,
+                      int ldr, const float* rvec, const float* g2, const float* be2, float eps2, float* out, int ldo,
+                      int out_pre_ln, void* out_hi, void* out_lo, int ldp, long long M, int K, int N, float cscale,
+                      float rscale, int waves, void* stream);
+
 /* Token-stationary single GEMM with the producer fused in front: per token row x [K] (fp32, row stride ldx)
  *     out = act( W1 . pre(x) + b1 ) * cvec * cscale       -> fp32 `out` [M, ldo] and / or bf16 hi / lo planes [M, ldp]
  * pre = identity or nn.LayerNorm's normalisation (affine part folded into W1 / b1 by the packer).  Same kernel family as

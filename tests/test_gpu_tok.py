@@ -244,3 +244,37 @@ def test_grl_block_head_proj_norm_mlp(M, per):
     back = pl.buf[0].float() + pl.buf[1].float()
     assert pl.Cp == 192 and bool((back[:, K:] == 0).all())
     assert (back[:, :K] - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item()
+
+
+@pytest.mark.parametrize("M,full", [(1000, True), (2051, False), (352 * 512 + 24, True)])
+def test_mamba_out_proj_with_gate_prologue_and_ln2(M, full):
+    """MambaIR's VSS tail as one kernel (mambair_arch.py:381-386, :417-419): a = out_norm(y0 + y1 + y2 + y3) * silu(z);
+    y = x * skip_scale + out_proj(a); planes <- ln_2(y), fp32 <- y.  `full` False: the plain projection (no prologue, no post-LN)."""
+    ops = mod("ops")
+    K, N = 360, 180
+    g = gen(M)
+    y4 = torch.randn(4, M, K, generator=g)
+    xz = torch.randn(M, 2 * K, generator=g)
+    x = torch.randn(M, N, generator=g)
+    w0 = torch.randn(N, K, generator=g) / K ** 0.5
+    pg, pb = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    g2, be2 = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    skip = torch.rand(N, generator=g) + 0.5
+    tg = ops.pack_tok_gemm(w0, None, DEV, check=False)
+    d = lambda t: t.to(DEV)
+    if not full:
+        want = F.linear(y4[0].double(), w0.double()) * 0.5 + x.double()
+        got = ops.tok_proj(d(y4)[0], tg, cscale=0.5, res=d(x))
+        assert rel(got, want) < 4e-5
+        return
+    z = xz[:, K:].double()
+    a = F.layer_norm(y4.double().sum(0), (K,), pg.double(), pb.double(), 1e-5) * F.silu(z)
+    y = x.double() * skip.double() + F.linear(a, w0.double())
+    n = F.layer_norm(y, (N,), g2.double(), be2.double(), 1e-5)
+    y4g, xzg = d(y4), d(xz)
+    got, pl = ops.tok_proj(y4g[0], tg, xdirs=4, xstride=y4g.stride(0), z=xzg[:, K:], pro_ln=(d(pg), d(pb)), res=d(x), rvec=d(skip),
+                           post_ln=(d(g2), d(be2)), out_pre_ln=True, out_planes=True)
+    assert rel(got, y) < 4e-5
+    back = pl.buf[0].float() + pl.buf[1].float()
+    assert pl.Cp == 192 and bool((back[:, N:] == 0).all())
+    assert rel(back[:, :N], n) < 4e-5
