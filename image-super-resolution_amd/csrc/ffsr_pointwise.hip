@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void dw3x3_run_kernel(const float* __restrict_
 // The columns of the next U = 4 (2 with the gate's two input halves) steps are in flight while the current U are computed.  The 4 waves of a workgroup take 4
 // vertically adjacent strips (their halo rows hit in L1 / the XCD's L2).  Same grid contract as dw3x3_run_kernel.
 template <bool GATE>
-__global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+__global__ __launch_bounds__(256, GATE ? 3 : 2) void dw3x3_strip_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                           float* __restrict__ part, int H, int W, int C, int nchunk, int act,
                                                           int XS) {
@@ -879,7 +879,7 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
   if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && pix >= 4096 && B <= 65535) {   // sliding-window kernel
     const long long per_img = (long long)H * W;
     const int nchunk = (int)(per_img / 256 < 1 ? 1 : (per_img / 256 > 8192 ? 8192 : per_img / 256));
-    if (H >= 16 && W >= 64 && pix * (ldi > ldo ? ldi : ldo) < (1ll << 31)) {
+    if (pix >= 65536 && W >= 64 && pix * (ldi > ldo ? ldi : ldo) < (1ll << 31)) {     // measured: 163 vs 227 us at 352 x 512 x 360
       const int xs = dw3x3_strip_width(H, W, (C + 63) / 64, B);
       const int ns = ((H + 3) / 4) * ((W + xs - 1) / xs);
       const int nck = (ns + 3) / 4 > 65535 ? 65535 : (ns + 3) / 4;
@@ -904,7 +904,9 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
 extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
                                         float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream) {
   FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
-  if (H >= 16 && W >= 64 && (long long)B * H * W * (ldi > ldo ? ldi : ldo) < (1ll << 31))     // (any nchunk: a workgroup walks the strips chunk * 4 + wave, + 4 nchunk, ...)
+  // measured (tools/dw_bench.py): wins only on the widest level (64 channels: 833 vs 1063 us at 1408 x 2048); with more channel
+  // groups the run kernel's 5 waves per SIMD x 36 loads in flight beat the strip kernel's 3 x 24
+  if (C <= 64 && (long long)H * W >= 65536 && W >= 64 && (long long)B * H * W * (ldi > ldo ? ldi : ldo) < (1ll << 31))     // (any nchunk: a workgroup walks the strips chunk * 4 + wave, + 4 nchunk, ...)
     FFSR_LAUNCH(dw3x3_strip_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
                        H, W, C, nchunk, 0, dw3x3_strip_width(H, W, (C + 63) / 64, B));
   else

@@ -141,6 +141,23 @@ def test_dwconv(ops, E, C, kh, kw, H, W):
     close(E.map_to_nchw(got), want, 1e-5, "dwconv")
 
 
+def test_dw3x3_strip_kernels(ops, E):
+    """the register-window strip kernels (>= 65536 pixels): odd sizes (rows % 4 != 0, a partial last strip, channels % 64 != 0),
+    a channel-slice input (MambaIR's x half of xz) and the gated + pooled form on NAFNet's widest level"""
+    C = 72
+    x, w, b = rnd(1, 2 * C, 262, 301, seed=4), rnd(C, 1, 3, 3, seed=5), rnd(C, seed=6)
+    want = F.silu(F.conv2d(x[:, :C], w, b, padding=1, groups=C))
+    got = ops.dwconv2d(E.nchw_to_map(x, DEV)[..., :C], ops.pack_dwconv(w, b, DEV), act=5)
+    close(E.map_to_nchw(got), want, 1e-5, "dwconv strip")
+    c = 64
+    x, w, b = rnd(2, 2 * c, 271, 250, seed=7), rnd(2 * c, 1, 3, 3, seed=8), rnd(2 * c, seed=9)
+    t = F.conv2d(x, w, b, padding=1, groups=2 * c)
+    want = t[:, :c] * t[:, c:]
+    g, pooled = ops.dw3x3_gate_pool(E.nchw_to_map(x, DEV), ops.pack_dwconv(w, b, DEV))
+    close(E.map_to_nchw(g), want, 1e-5, "gate strip")
+    close(pooled.cpu(), want.mean((2, 3)), 1e-5, "pool strip")
+
+
 def test_dw3x3_gate_pool(ops, E):
     c = 96
     x, w, b = rnd(2, 2 * c, 21, 17, seed=1), rnd(2 * c, 1, 3, 3, seed=2), rnd(2 * c, seed=3)
