@@ -4,6 +4,7 @@
 // A tensor is a matrix [M pixels, C channels] with a row stride ld (floats, multiple of 4 so that every row is
 // 16-byte aligned); lanes run along channels so every wave access is a contiguous row segment.
 #include "ffsr_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -746,12 +747,34 @@ __global__ void dihedral_kernel(const float* __restrict__ in, int ldi, float* __
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// strip width of dw3x3_strip_kernel: as long as possible (the 2-column lead-in of a strip is its only overhead) while the launch
-// still has >= ~8 waves per SIMD-slot of the chip to balance (4096 waves)
+// FFSR_DW_STRIP=0 keeps the run kernel everywhere (A/B measurements, tools/dw_bench.py)
+inline bool dw3x3_strip_enabled() {
+  static const int on = [] {
+    const char* e = getenv("FFSR_DW_STRIP");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return on != 0;
+}
+
+inline int dw3x3_strip_maxc() {
+  static const int c = [] {
+    const char* e = getenv("FFSR_DW_STRIP_MAXC");
+    return e ? atoi(e) : 64;
+  }();
+  return c;
+}
+
+// strip width of dw3x3_strip_kernel: the launch should have >= 8192 waves (measured: 1408 x 2048 x 64 gated 1504 / 830 / 506 /
+// 566 us with strips cut for 2048 / 4096 / 8192 / 16384 waves -- short strips keep more independent load streams in flight and
+// balance better than long ones save on their 2-column lead-in)
 inline int dw3x3_strip_width(int H, int W, int cgroups, int B) {
   const long long rows = (long long)((H + 3) / 4) * cgroups * B;
+  static const int target = [] {
+    const char* e = getenv("FFSR_DW_STRIP_WAVES");
+    return e ? atoi(e) : 8192;
+  }();
   int xs = 512;
-  while (xs > 32 && rows * ((W + xs - 1) / xs) < 4096) xs >>= 1;
+  while (xs > 32 && rows * ((W + xs - 1) / xs) < target) xs >>= 1;
   return xs;
 }
 
@@ -879,7 +902,7 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
   if (KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && pix >= 4096 && B <= 65535) {   // sliding-window kernel
     const long long per_img = (long long)H * W;
     const int nchunk = (int)(per_img / 256 < 1 ? 1 : (per_img / 256 > 8192 ? 8192 : per_img / 256));
-    if (pix >= 65536 && W >= 64 && pix * (ldi > ldo ? ldi : ldo) < (1ll << 31)) {     // measured: 163 vs 227 us at 352 x 512 x 360
+    if (dw3x3_strip_enabled() && pix >= 65536 && W >= 64 && pix * (ldi > ldo ? ldi : ldo) < (1ll << 31)) {     // measured: 163 vs 227 us at 352 x 512 x 360
       const int xs = dw3x3_strip_width(H, W, (C + 63) / 64, B);
       const int ns = ((H + 3) / 4) * ((W + xs - 1) / xs);
       const int nck = (ns + 3) / 4 > 65535 ? 65535 : (ns + 3) / 4;
@@ -904,9 +927,10 @@ extern "C" int ffsr_dwconv2d_f32(const float* in, int ldi, const float* w, const
 extern "C" int ffsr_dw3x3_gate_pool_f32(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
                                         float* pooled, float* part, int B, int H, int W, int C, int nchunk, void* stream) {
   FFSR_CHECK(in && w && bias && out && pooled && part && B > 0 && H > 0 && W > 0 && C > 0 && nchunk > 0 && nchunk <= 65535);
-  // measured (tools/dw_bench.py): wins only on the widest level (64 channels: 833 vs 1063 us at 1408 x 2048); with more channel
-  // groups the run kernel's 5 waves per SIMD x 36 loads in flight beat the strip kernel's 3 x 24
-  if (C <= 64 && (long long)H * W >= 65536 && W >= 64 && (long long)B * H * W * (ldi > ldo ? ldi : ldo) < (1ll << 31))     // (any nchunk: a workgroup walks the strips chunk * 4 + wave, + 4 nchunk, ...)
+  // measured (tools/dw_bench.py, strips of >= 8192 waves): wins on the widest level (64 channels: 506 vs 1065 us at 1408 x 2048,
+  // 257 vs 288 us at 1024 x 1024); from 128 channels on the run kernel's 5 waves per SIMD x 36 loads in flight are as fast or
+  // faster (352 x 512 x 256: 200 vs 325 us)
+  if (dw3x3_strip_enabled() && C <= dw3x3_strip_maxc() && (long long)H * W >= 65536 && W >= 64 && (long long)B * H * W * (ldi > ldo ? ldi : ldo) < (1ll << 31))     // (any nchunk: a workgroup walks the strips chunk * 4 + wave, + 4 nchunk, ...)
     FFSR_LAUNCH(dw3x3_strip_kernel<true>, dim3((C + 63) / 64, nchunk, B), dim3(256), 0, ST, in, ldi, w, bias, out, ldo, part,
                        H, W, C, nchunk, 0, dw3x3_strip_width(H, W, (C + 63) / 64, B));
   else

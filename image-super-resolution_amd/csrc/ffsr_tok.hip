@@ -166,8 +166,10 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
 
 // The head's result row (bias already added; tile (s, g) of lane (token, q) = columns 32 s + 8 q + 4 g + 0..3):
 //   hv = LN0?(hv) + hres + hres2 * hvec2[batch];  columns >= K stay zero (they are the k padding of the chain's first GEMM)
-template <int KS1>
-__device__ __forceinline__ void tok_head_epilogue(const TokArgs& p, floatx4 (&hv)[KS1][2], size_t row, int q) {
+// HPF: the hres rows were prefetched into hr together with the head's input rows (narrow shapes, where a second exposed load
+// phase per tile costs more than the 2 KS1 x 4 registers).
+template <int KS1, bool HPF>
+__device__ __forceinline__ void tok_head_epilogue(const TokArgs& p, floatx4 (&hv)[KS1][2], const floatx4 (&hr)[KS1][2], size_t row, int q) {
   const int N = p.K;
   if (p.g0) {
     float s1 = 0.f;
@@ -210,7 +212,8 @@ __device__ __forceinline__ void tok_head_epilogue(const TokArgs& p, floatx4 (&hv
     for (int h = 0; h < 2; ++h) {
       const int col = 32 * s + 8 * q + 4 * h;
       if (col < N) {
-        if (p.hres) hv[s][h] += *reinterpret_cast<const floatx4*>(p.hres + row * p.ldhr + col);
+        if constexpr (HPF) hv[s][h] += hr[s][h];
+        else if (p.hres) hv[s][h] += *reinterpret_cast<const floatx4*>(p.hres + row * p.ldhr + col);
         if (p.hres2) {
           floatx4 r = *reinterpret_cast<const floatx4*>(p.hres2 + row * p.ldhr2 + col);
           if (v2) r *= *reinterpret_cast<const floatx4*>(v2 + col);
@@ -367,11 +370,15 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
     return (size_t)(ok ? tok : p.M - 1);
   };
 
+  constexpr bool HPF = HEAD && PFETCH && MODE != 3 && KS1 <= 4;      // the head's residual rows travel with its input rows
   floatx4 xv[KSL][2];      // the rows of the tile about to be computed (fp32)
+  floatx4 hr[KS1][2];      // HPF: the hres rows of that tile (zeros without an hres)
   {
     long long t_;
     bool o_;
-    tok_load_rows<KSL>(p.x + tile_row(blockIdx.x, t_, o_) * p.ldx, KL, q, xv);
+    const size_t r_ = tile_row(blockIdx.x, t_, o_);
+    tok_load_rows<KSL>(p.x + r_ * p.ldx, KL, q, xv);
+    if constexpr (HPF) tok_load_rows<KS1>(p.hres + r_ * p.ldhr, p.hres ? p.K : 0, q, hr);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bias stores (before the first barrier)
 
@@ -398,16 +405,37 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       const int nt = min(tile + (int)gridDim.x, ntile - 1);
       long long t_;
       bool o_;
-      tok_load_rows<KSL>(p.x + tile_row(nt, t_, o_) * p.ldx, KL, q, xv);
+      const size_t r_ = tile_row(nt, t_, o_);
+      tok_load_rows<KSL>(p.x + r_ * p.ldx, KL, q, xv);
+      if constexpr (HPF) tok_load_rows<KS1>(p.hres + r_ * p.ldhr, p.hres ? p.K : 0, q, hr);
     };
     if constexpr (!HEAD && PFETCH) fetch_next();
 
     if constexpr (HEAD) {
       // ---- head GEMM: 32 output features per step (two tiles over all KS0 k steps), results in the chain's operand order
+      floatx4 hrc[KS1][2];      // (this tile's residual rows: hr is about to be refilled for the next tile)
+      if constexpr (HPF) {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+          hrc[s][0] = hr[s][0];
+          hrc[s][1] = hr[s][1];
+        }
+      }
       {
         bf16x8 i_hi[KS0], i_lo[KS0];
         if constexpr (MODE == 3) {
           if (p.xdirs == 4 || p.pg || p.z) tok_gate_prologue<KS0>(p, p.x + row * p.ldx, row, q, xv);
+        } else {
+          if (p.hxs) {
+            const float* v = p.hxs + (row / (size_t)p.rows_per_batch) * p.K0;
+#pragma unroll
+            for (int s = 0; s < KS0; ++s)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int col = 32 * s + 8 * q + 4 * h;
+                if (col < p.K0) xv[s][h] *= *reinterpret_cast<const floatx4*>(v + col);
+              }
+          }
         }
         tok_prepare<KS0>(p.K0, false, 0.f, q, xv, i_hi, i_lo);
         if constexpr (PFETCH) fetch_next();
@@ -439,7 +467,7 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
         }
       }
       if constexpr (MODE != 3) {
-        tok_head_epilogue<KS1>(p, hv, row, q);
+        tok_head_epilogue<KS1, HPF>(p, hv, hrc, row, q);
         tok_prepare<KS1>(p.K, p.pre_ln != 0, p.eps1, q, hv, a_hi, a_lo);
       }
     }
@@ -713,6 +741,7 @@ struct TokHead {
   int ldhr2;
   const float* hvec2;
   int rows_per_batch;
+  const float* hxs;
 };
 
 int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
@@ -724,7 +753,8 @@ int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, c
   const bool tail = w3 != nullptr;
   FFSR_CHECK(x && w1 && b1 && w2 && (out || (out_hi && out_lo) || tail) && M > 0 && M < (1ll << 31));
   if (hd) {       // the loaded rows are the head's input (K0 = K channels); the chain's own input never exists in memory
-    FFSR_CHECK(hd->w0 && hd->b0 && ((uintptr_t)hd->w0 & 15) == 0 && mode == 0 && K == N && !res && !res2 && !cvec && !rvec);
+    FFSR_CHECK(hd->w0 && hd->b0 && ((uintptr_t)hd->w0 & 15) == 0 && K == N && !res && !res2 && !cvec && !rvec);
+    FFSR_CHECK(!hd->hxs || (hd->rows_per_batch > 0 && ((uintptr_t)hd->hxs & 15) == 0));
     FFSR_CHECK(!hd->g0 || (hd->be0 && ((uintptr_t)hd->g0 & 15) == 0 && ((uintptr_t)hd->be0 & 15) == 0));
     FFSR_CHECK(!hd->hres || (hd->ldhr >= K && (hd->ldhr & 3) == 0 && ((uintptr_t)hd->hres & 15) == 0));
     FFSR_CHECK(!hd->hres2 || (hd->ldhr2 >= K && (hd->ldhr2 & 3) == 0 && ((uintptr_t)hd->hres2 & 15) == 0));
@@ -741,6 +771,7 @@ int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, c
              (!g2 || (((uintptr_t)g2 & 15) == 0 && ((uintptr_t)be2 & 15) == 0)));
   FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= N && ldp < N + 32 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0));
   FFSR_CHECK(mode == 0 || mode == 1);
+  FFSR_CHECK(!hd || !g2 || mode == 0);
   if (tail) {
     FFSR_CHECK(b3 && out3 && N3 > 0 && (N3 & 3) == 0 && ldo3 >= N3 && (ldo3 & 3) == 0 && ((uintptr_t)out3 & 15) == 0 && ((uintptr_t)w3 & 15) == 0);
     FFSR_CHECK(!res3 || (ldr3 >= N3 && (ldr3 & 3) == 0 && ((uintptr_t)res3 & 15) == 0));
@@ -763,10 +794,16 @@ int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, c
   if (waves == 0) waves = 8;
   if (hd) {
     a.w0 = (const unsigned char*)hd->w0; a.b0 = hd->b0; a.g0 = hd->g0; a.be0 = hd->be0; a.hres = hd->hres; a.hres2 = hd->hres2;
-    a.hvec2 = hd->hvec2; a.K0 = K; a.ldhr = hd->ldhr; a.ldhr2 = hd->ldhr2; a.rows_per_batch = hd->rows_per_batch;
+    a.hvec2 = hd->hvec2; a.hxs = hd->hxs; a.K0 = K; a.ldhr = hd->ldhr; a.ldhr2 = hd->ldhr2; a.rows_per_batch = hd->rows_per_batch;
     a.hsteps = ks1; a.eps0 = hd->eps0;
     // without a post-LN the chain is x1 + mlp(norm(x1)) (RX: accumulators start from x1); with one it is norm(mlp(x1)) + x1
     a.res_is_x = g2 ? 0 : 1;
+    if (mode == 1) {      // NAFNet: conv3 (+ channel attention, beta) in front of the gated half, c = 64 / 128
+      if (!a.res_is_x) return FFSR_EINVAL;
+      if (ks1 == 2 && nt2 == 4) return launch_tok_w<2, 4, 1, true, 2>(a, waves, st);
+      if (ks1 == 4 && nt2 == 8) return launch_tok_w<4, 8, 1, true, 4>(a, waves, st);
+      return FFSR_EINVAL;
+    }
     if (!a.res_is_x) return (ks1 == 6 && nt2 == 12) ? launch_tok_w<6, 12, 0, false, 6>(a, waves, st) : FFSR_EINVAL;   // GRL: C = 180
 #define FFSR_TOK_HEAD_CASE(KS, NT) \
   if (ks1 == KS && nt2 == NT) return launch_tok_w<KS, NT, 0, true, KS>(a, waves, st)
@@ -850,17 +887,18 @@ extern "C" int ffsr_tok_gemm_f32(const float* x, int ldx, const void* w1, const 
 }
 
 // See include/ffsr.h for the contract.
-extern "C" int ffsr_tok_head_chain_f32(const float* a, int lda, const void* w0, const float* b0, const float* g0, const float* be0,
-                                       float eps0, const float* hres, int ldhr, const float* hres2, int ldhr2, const float* hvec2,
-                                       int rows_per_batch, const void* w1, const float* b1, const void* w2, const float* b2,
-                                       const float* g2, const float* be2, float eps2, float* out, int ldo, void* out_hi,
-                                       void* out_lo, int ldp, long long M, int K, int steps, int pre_ln, float eps1,
+extern "C" int ffsr_tok_head_chain_f32(const float* a, int lda, const float* ascale, const void* w0, const float* b0, const float* g0,
+                                       const float* be0, float eps0, const float* hres, int ldhr, const float* hres2, int ldhr2,
+                                       const float* hvec2, int rows_per_batch, const void* w1, const float* b1, const void* w2,
+                                       const float* b2, const float* g2, const float* be2, float eps2, float* out, int ldo,
+                                       void* out_hi, void* out_lo, int ldp, long long M, int K, int steps, int mode, int pre_ln,
+                                       float eps1,
                                        const void* w3, const float* b3, const float* res3, int ldr3, float* out3, int ldo3,
                                        int N3, int act3, float slope3, float cscale3, float rscale3, int waves, void* stream) {
   FFSR_CHECK(w0 && b0);
-  const TokHead hd = {w0, b0, g0, be0, eps0, hres, ldhr, hres2, ldhr2, hvec2, rows_per_batch};
+  const TokHead hd = {w0, b0, g0, be0, eps0, hres, ldhr, hres2, ldhr2, hvec2, rows_per_batch, ascale};
   return tok_chain_common(a, lda, w1, b1, w2, b2, nullptr, nullptr, 0, nullptr, g2, be2, nullptr, 0, out, ldo, out_hi, out_lo, ldp, M,
-                          K, K, steps, 0, pre_ln, eps1, eps2, 1.f, 1.f, waves, w3, b3, res3, ldr3, out3, ldo3, N3, act3, slope3,
+                          K, K, steps, mode, pre_ln, eps1, eps2, 1.f, 1.f, waves, w3, b3, res3, ldr3, out3, ldo3, N3, act3, slope3,
                           cscale3, rscale3, stream, &hd);
 }
 

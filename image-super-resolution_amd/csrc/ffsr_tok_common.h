@@ -54,6 +54,7 @@ struct TokArgs {
   const float* hres;         // [M, ldhr] or null
   const float* hres2;        // [M, ldhr2] or null
   const float* hvec2;        // [batches, K] or null (1)
+  const float* hxs;          // [batches, K0] or null: per-image channel scale of the head's INPUT row (NAFNet's channel attention)
   int K0, ldhr, ldhr2, rows_per_batch, hsteps, out_pre_ln;
   float eps0;
   // MODE 3 prologue (MambaIR's out_norm + gate in front of out_proj, mambair_arch.py:381-385): the head's input row is

@@ -44,6 +44,17 @@ class _Block:
                                           sd[p + "conv5.bias"].detach().float() * gam.to(w5.device), device, mode=1,
                                           ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]), eps=1e-6)
 
+        # ... and conv3 (with the channel attention on its input and beta on its output) as the HEAD of that kernel:
+        # y = x + beta * conv3(gated * sca) stays in registers (nafnet_arch.py:122-125)
+        self.conv3_t = None
+        # (c = 128 only: at c = 64 the pass is pure streaming -- measured 854 us fused against 413 + 420 us for conv3 and the
+        #  gated half as two launches at 1408 x 2048, and slower still at 1024 x 1024; at c = 128 546 against 629 us)
+        if self.ffn is not None and c == 128 and ops.tok_gemm_ok(c, c):
+            bet = sd[p + "beta"].detach().float().reshape(-1)
+            w3 = sd[p + "conv3.weight"].detach().float().reshape(c, c)
+            self.conv3_t = ops.pack_tok_gemm(w3 * bet[:, None].to(w3.device), sd[p + "conv3.bias"].detach().float() * bet.to(w3.device),
+                                             device)
+
     def __call__(self, x):
         c = self.c
         # deep levels (c >= 256: long K, few pixels) are MFMA-heavy: their LayerNorm outputs go to the GEMM as bf16
@@ -57,6 +68,10 @@ class _Block:
             t = ops.conv2d(t, self.conv1)
         g, pooled = ops.dw3x3_gate_pool(t, self.dw)              # SimpleGate + global average pool
         sca = ops.linear(pooled, self.sca)                       # [B, c] channel attention
+        if self.conv3_t is not None and ops.tok_enabled() and ops.HEAD_FUSED and ops.rows(x) > 64 * 24:
+            B, H, W, _ = x.shape
+            return to_map(ops.tok_head_chain(tokens(g), self.conv3_t, self.ffn, in_scale=sca.contiguous(), hres=tokens(x),
+                                             rows_per_batch=H * W), B, H, W)
         y = ops.conv2d(g, self.conv3, akscale=sca.contiguous(), res=x, cvec=self.beta)   # x + conv3(g*sca)*beta
         B, H, W, _ = y.shape
         if self.ffn is not None and ops.tok_enabled() and B * H * W > 64 * 24:

@@ -654,12 +654,13 @@ def tok_chain(x2d, tc: TokChain, *, res=None, rscale=1.0, rvec=None, cvec=None, 
     return out
 
 
-def tok_head_chain(a2d, head: TokGemm, tc: TokChain, *, head_ln=None, eps0=1e-5, hres=None, hres2=None, hvec2=None,
+def tok_head_chain(a2d, head: TokGemm, tc: TokChain, *, in_scale=None, head_ln=None, eps0=1e-5, hres=None, hres2=None, hvec2=None,
                    rows_per_batch=0, post_ln=None, eps2=1e-5, out=None, out_planes=None, want_f32=True, tail=None):
     """a2d [M, K] -> the chain `tc` applied to x1 = LN0?(head(a)) + hres + hres2 * hvec2[batch], one kernel, x1 never stored
     (ffsr_tok_head_chain_f32).  post_ln None: y = x1 + mlp(pre(x1)); (gamma, beta): y = LN(mlp(x1)) + x1.
     Returns like tok_chain (out / planes / tail output)."""
-    assert a2d.dim() == 2 and a2d.stride(1) == 1 and head.K == head.N == tc.K == tc.N and not head.pre_ln and tc.mode == 0
+    assert a2d.dim() == 2 and a2d.stride(1) == 1 and head.K == head.N == tc.K == tc.N and not head.pre_ln and tc.mode in (0, 1)
+    assert in_scale is None or (in_scale.is_contiguous() and in_scale.shape[-1] == head.K and rows_per_batch > 0)
     M = a2d.shape[0]
     out3 = None
     if tail is not None:
@@ -676,12 +677,12 @@ def tok_head_chain(a2d, head: TokGemm, tc: TokChain, *, head_ln=None, eps0=1e-5,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    hip.call("ffsr_tok_head_chain_f32", _ptr(a2d), a2d.stride(0), _ptr(head.w1), _ptr(head.b1), _ptr(g0), _ptr(be0), float(eps0),
+    hip.call("ffsr_tok_head_chain_f32", _ptr(a2d), a2d.stride(0), _ptr(in_scale), _ptr(head.w1), _ptr(head.b1), _ptr(g0), _ptr(be0), float(eps0),
              _ptr(hres), 0 if hres is None else hres.stride(0), _ptr(hres2), 0 if hres2 is None else hres2.stride(0), _ptr(hvec2),
              int(rows_per_batch), _ptr(tc.w1), _ptr(tc.b1), _ptr(tc.w2), _ptr(tc.b2), _ptr(g2), _ptr(be2), float(eps2), _ptr(out),
              0 if out is None else out.stride(0), None if out_planes is None else _ptr(out_planes.hi),
              None if out_planes is None else _ptr(out_planes.lo), 0 if out_planes is None else out_planes.Cp, M, tc.K, tc.steps,
-             int(tc.pre_ln), tc.eps1, None if tail is None else _ptr(tail["tg"].w1), None if tail is None else _ptr(tail["tg"].b1),
+             tc.mode, int(tc.pre_ln), tc.eps1, None if tail is None else _ptr(tail["tg"].w1), None if tail is None else _ptr(tail["tg"].b1),
              _ptr(r3), 0 if r3 is None else r3.stride(0), _ptr(out3), 0 if out3 is None else out3.stride(0),
              0 if tail is None else tail["tg"].N, ACT_NONE if tail is None else tail.get("act", ACT_NONE),
              0.0 if tail is None else float(tail.get("slope", 0.0)), 1.0 if tail is None else float(tail.get("cscale", 1.0)),

@@ -121,14 +121,17 @@ int ffsr_tok_chain_tail_f32(const float* x, int ldx, const void* w1, const float
  * x1 = x + norm1(proj(attention)) + conv_branch * channel_attention, mixed_attn_block_efficient.py:536-554 -- hres = x,
  * hres2 = the CAB convolution output, hvec2 = its per-image channel-attention scale [batches, K]).  y -> out / planes as in
  * ffsr_tok_chain_f32; the optional tail (w3 != NULL) as in ffsr_tok_chain_tail_f32.  w0 / b0 in the ffsr_tok_gemm_f32 packing.
+ * ascale [batches, K] (or NULL): the head's input row is first scaled per image and channel; mode 1 = the gated chain:
+ * NAFBlock  y = x + beta * conv3(gated * sca);  out = y + gamma * conv5(SimpleGate(conv4(norm2(y))))   (nafnet_arch.py:122-131;
+ * beta / gamma folded into W0 / W2 by the packer, hres = x, ascale = the channel attention sca, K = 64 or 128).
  * Replaces three launches (proj GEMM, residual / LayerNorm kernel, MLP chain) and the two HBM round trips between them. */
-int ffsr_tok_head_chain_f32(const float* a, int lda, const void* w0, const float* b0, const float* g0, const float* be0,
-                            float eps0, const float* hres, int ldhr, const float* hres2, int ldhr2, const float* hvec2,
-                            int rows_per_batch, const void* w1, const float* b1, const void* w2, const float* b2,
-                            const float* g2, const float* be2, float eps2, float* out, int ldo, void* out_hi, void* out_lo,
-                            int ldp, long long M, int K, int steps, int pre_ln, float eps1, const void* w3, const float* b3,
-                            const float* res3, int ldr3, float* out3, int ldo3, int N3, int act3, float slope3, float cscale3,
-                            float rscale3, int waves, void* stream);
+int ffsr_tok_head_chain_f32(const float* a, int lda, const float* ascale, const void* w0, const float* b0, const float* g0,
+                            const float* be0, float eps0, const float* hres, int ldhr, const float* hres2, int ldhr2,
+                            const float* hvec2, int rows_per_batch, const void* w1, const float* b1, const void* w2,
+                            const float* b2, const float* g2, const float* be2, float eps2, float* out, int ldo, void* out_hi,
+                            void* out_lo, int ldp, long long M, int K, int steps, int mode, int pre_ln, float eps1,
+                            const void* w3, const float* b3, const float* res3, int ldr3, float* out3, int ldo3, int N3,
+                            int act3, float slope3, float cscale3, float rscale3, int waves, void* stream);
 
 /* Token-stationary projection with a full-row epilogue (and MambaIR's out_norm / gate as its prologue), one kernel:
  *     a   = x                                                       (xdirs == 1)

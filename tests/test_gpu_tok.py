@@ -278,3 +278,25 @@ def test_mamba_out_proj_with_gate_prologue_and_ln2(M, full):
     back = pl.buf[0].float() + pl.buf[1].float()
     assert pl.Cp == 192 and bool((back[:, N:] == 0).all())
     assert rel(back[:, :N], n) < 4e-5
+
+
+@pytest.mark.parametrize("c,M,per", [(64, 3000, 1500), (128, 1111, 1111), (64, 1024 * 96 + 8, 1024 * 96 + 8)])
+def test_nafnet_block_head_conv3_sca_gated_half(c, M, per):
+    """NAFBlock from the gated map on, one kernel (nafnet_arch.py:122-131): y = x + beta * conv3(g * sca[image]);
+    out = y + gamma * conv5(SimpleGate(conv4(LayerNorm2d(y))))  (eps 1e-6); y is never stored."""
+    ops = mod("ops")
+    gn = gen(c + M)
+    x, g = torch.randn(M, c, generator=gn), torch.randn(M, c, generator=gn)
+    sca = torch.rand(M // per, c, generator=gn) + 0.5
+    w3, b3 = torch.randn(c, c, generator=gn) / c ** 0.5, torch.randn(c, generator=gn) * 0.1
+    beta, gamma = torch.randn(c, generator=gn) * 0.5, torch.randn(c, generator=gn) * 0.5
+    n2w, n2b = torch.rand(c, generator=gn) + 0.5, torch.randn(c, generator=gn) * 0.1
+    w4, b4 = torch.randn(2 * c, c, generator=gn) / c ** 0.5, torch.randn(2 * c, generator=gn) * 0.1
+    w5, b5 = torch.randn(c, c, generator=gn) / c ** 0.5, torch.randn(c, generator=gn) * 0.1
+    y = x.double() + beta.double() * F.linear(g.double() * sca.double().repeat_interleave(per, 0), w3.double(), b3.double())
+    t = F.linear(F.layer_norm(y, (c,), n2w.double(), n2b.double(), 1e-6), w4.double(), b4.double())
+    want = y + gamma.double() * F.linear(t[:, :c] * t[:, c:], w5.double(), b5.double())
+    head = ops.pack_tok_gemm(w3 * beta[:, None], b3 * beta, DEV)
+    tc = ops.pack_tok_chain(w4, b4, w5 * gamma[:, None], b5 * gamma, DEV, mode=1, ln=(n2w, n2b), eps=1e-6)
+    got = ops.tok_head_chain(g.to(DEV), head, tc, in_scale=sca.to(DEV), hres=x.to(DEV), rows_per_batch=per)
+    assert rel(got, want) < 4e-5

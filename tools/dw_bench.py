@@ -25,7 +25,7 @@ def timeit(fn, n=10):
 
 
 g = torch.Generator().manual_seed(0)
-for (H, W, C) in ((1408, 2048, 64), (704, 1024, 128), (352, 512, 256), (176, 256, 512), (88, 128, 1024)):
+for (H, W, C) in ((1408, 2048, 64), (1024, 1024, 64), (512, 512, 128), (704, 1024, 128), (352, 512, 256), (176, 256, 512), (88, 128, 1024)):
     x = torch.randn(1, H, W, 2 * C, generator=g).to(dev)
     dw = ops.pack_dwconv(torch.randn(2 * C, 1, 3, 3, generator=g), torch.randn(2 * C, generator=g), dev)
     us = timeit(lambda: ops.dw3x3_gate_pool(x, dw))
