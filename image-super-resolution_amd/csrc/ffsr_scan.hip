@@ -41,6 +41,8 @@ struct ScanArgs {
   float* hstate;      // [B, 4, nchunk, Dm, NS]  local end state (pass A) -> incoming state (pass B)
   float* decay;       // [B, 4, nchunk, Dm, NS]
   int B, H, W, L, Dm, ldu, ldx, ldy, R, chunk, nchunk;
+  int kbase, nk;      // this launch covers the directions kbase .. kbase + nk - 1 (scratch is indexed by the local direction)
+  int pairs;          // 1: y has TWO planes -- direction k writes plane k & 1, the directions 2 and 3 ADD to what 0 and 1 wrote
 };
 
 __device__ __forceinline__ int tok_pixel(int k, int t, int H, int W, int L) {
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(64, 4) void scan_chunk_kernel(ScanArgs p) {
   const int lane = threadIdx.x;
   const int d = blockIdx.x * 64 + lane;
   const int c = blockIdx.y;
-  const int k = blockIdx.z & 3, b = blockIdx.z >> 2;
+  const int kl = blockIdx.z % p.nk, b = blockIdx.z / p.nk;
+  const int k = p.kbase + kl;
   const bool live = d < p.Dm;
   const int dd = live ? d : p.Dm - 1;
   float w[R], a2[NS], h[NS];
@@ -81,23 +84,26 @@ __global__ __launch_bounds__(64, 4) void scan_chunk_kernel(ScanArgs p) {
   for (int n = 0; n < NS; ++n) a2[n] = p.A[((size_t)k * p.Dm + dd) * NS + n] * 1.4426950408889634f;  // exp(x) = 2^(x log2 e)
   const float bias = p.dtb[k * p.Dm + dd];
   const float dskip = p.Dv[k * p.Dm + dd];
-  const size_t sidx = ((((size_t)b * 4 + k) * p.nchunk + c) * p.Dm + dd) * NS;
+  const size_t sidx = ((((size_t)b * p.nk + kl) * p.nchunk + c) * p.Dm + dd) * NS;
 #pragma unroll
   for (int n = 0; n < NS; ++n) h[n] = EMIT ? p.hstate[sidx + n] : 0.f;
   float dsum = 0.f;
   const int t0 = c * p.chunk, t1 = min(p.L, t0 + p.chunk);
   const float* ub = p.u + (size_t)b * p.L * p.ldu;
   const float* xb = p.xdbl + (size_t)b * p.L * p.ldx + k * XW;
-  float* yb = p.y + ((size_t)k * p.B + b) * p.L * p.ldy;
+  float* yb = p.y + ((size_t)(p.pairs ? (k & 1) : k) * p.B + b) * p.L * p.ldy;
+  const bool accum = EMIT && p.pairs && k >= 2;      // (wave-uniform)
 
   float u_cur[G], u_nxt[G], x_nxt[XN];
+  float yo_cur[G], yo_nxt[G];                        // accum: what the first pair left at the pixels of the group
   int pix_cur[G], pix_nxt[G];
   auto fetch = [&](int tg) {  // global -> registers for the group starting at step tg
     const int mypix = tok_pixel(k, min(tg + (lane & (G - 1)), p.L - 1), p.H, p.W, p.L);
 #pragma unroll
     for (int r = 0; r < G; ++r) {
-      pix_nxt[r] = __shfl(mypix, r, 64);
+      pix_nxt[r] = __builtin_amdgcn_readlane(mypix, r);      // wave-uniform: lives in a scalar register
       u_nxt[r] = ub[(size_t)pix_nxt[r] * p.ldu + dd];
+      if (EMIT) yo_nxt[r] = accum ? yb[(size_t)pix_nxt[r] * p.ldy + dd] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < XN; ++i) {
@@ -115,6 +121,7 @@ __global__ __launch_bounds__(64, 4) void scan_chunk_kernel(ScanArgs p) {
     for (int r = 0; r < G; ++r) {
       u_cur[r] = u_nxt[r];
       pix_cur[r] = pix_nxt[r];
+      if (EMIT) yo_cur[r] = yo_nxt[r];
     }
   };
   fetch(t0);
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(64, 4) void scan_chunk_kernel(ScanArgs p) {
           if (EMIT) yv = fmaf(xr[R + NS + n], h[n], yv);
         }
         if (EMIT) {
-          if (live) yb[(size_t)pix_cur[r] * p.ldy + d] = fmaf(dskip, uu, yv);
+          if (live) yb[(size_t)pix_cur[r] * p.ldy + d] = fmaf(dskip, uu, yv) + yo_cur[r];
         } else {
           dsum += delta;
         }
@@ -267,7 +274,8 @@ __global__ __launch_bounds__(256) void mamba_norm_gate_v8_kernel(const float* __
                                                                  const float* __restrict__ g, const float* __restrict__ be,
                                                                  float eps, float* __restrict__ out, int ldo,
                                                                  unsigned short* __restrict__ ohi,
-                                                                 unsigned short* __restrict__ olo, int ldp, int M, int C) {
+                                                                 unsigned short* __restrict__ olo, int ldp, int M, int C,
+                                                                 int ndir) {
   const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int l = threadIdx.x & 31;
   if (row >= M) return;
@@ -282,8 +290,11 @@ __global__ __launch_bounds__(256) void mamba_norm_gate_v8_kernel(const float* __
       if (c < C) {
         const float* p0 = y + (size_t)row * ldy + c;
         // y1+y2+y3+y4 in the order of mambair_arch.py:381
-        t = ((*reinterpret_cast<const floatx4*>(p0) + *reinterpret_cast<const floatx4*>(p0 + 2 * ystride)) +
-             *reinterpret_cast<const floatx4*>(p0 + ystride)) + *reinterpret_cast<const floatx4*>(p0 + 3 * ystride);
+        if (ndir == 4)
+          t = ((*reinterpret_cast<const floatx4*>(p0) + *reinterpret_cast<const floatx4*>(p0 + 2 * ystride)) +
+               *reinterpret_cast<const floatx4*>(p0 + ystride)) + *reinterpret_cast<const floatx4*>(p0 + 3 * ystride);
+        else        // the pair planes of ffsr_selective_scan4_pairs_f32: (y0 + y2) + (y1 + y3)
+          t = *reinterpret_cast<const floatx4*>(p0) + *reinterpret_cast<const floatx4*>(p0 + ystride);
       }
       v[p][hh] = t;
       s += (t[0] + t[1]) + (t[2] + t[3]);
@@ -329,9 +340,9 @@ __global__ __launch_bounds__(256) void mamba_norm_gate_v8_kernel(const float* __
 
 template <int R>
 int run_scan(const ScanArgs& a, hipStream_t st) {
-  dim3 grid((a.Dm + 63) / 64, a.nchunk, 4 * a.B);
+  dim3 grid((a.Dm + 63) / 64, a.nchunk, a.nk * a.B);
   FFSR_LAUNCH((scan_chunk_kernel<R, false>), grid, dim3(64), 0, st, a);
-  FFSR_LAUNCH(scan_carry_kernel, dim3((a.Dm * NS + 63) / 64, a.B * 4), dim3(64 * CARRY_SEG), 0, st, a.hstate, a.decay,
+  FFSR_LAUNCH(scan_carry_kernel, dim3((a.Dm * NS + 63) / 64, a.B * a.nk), dim3(64 * CARRY_SEG), 0, st, a.hstate, a.decay,
                      a.nchunk, a.Dm * NS);
   FFSR_LAUNCH((scan_chunk_kernel<R, true>), grid, dim3(64), 0, st, a);
   return ffsr_launch_status();
@@ -339,10 +350,10 @@ int run_scan(const ScanArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw,
-                                        const float* dtb, const float* A, const float* Dv, float* y, int ldy,
-                                        float* hstate, float* decay, int B, int H, int W, int Dm, int R, int d_state,
-                                        int chunk, void* stream) {
+namespace {
+int scan_common(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw, const float* dtb, const float* A,
+                const float* Dv, float* y, int ldy, float* hstate, float* decay, int B, int H, int W, int Dm, int R, int d_state,
+                int chunk, int pairs, void* stream) {
   FFSR_CHECK(u && xdbl && dtw && dtb && A && Dv && y && hstate && decay);
   FFSR_CHECK(B > 0 && H > 0 && W > 0 && Dm > 0 && d_state == NS && chunk > 0);
   FFSR_CHECK(ldu >= Dm && ldy >= Dm && ldx >= 4 * (R + 2 * NS));
@@ -352,24 +363,49 @@ extern "C" int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xd
   a.nchunk = (a.L + chunk - 1) / chunk;
   FFSR_CHECK(a.nchunk <= 65535 && 4 * B <= 65535);
   hipStream_t st = (hipStream_t)stream;
-  switch (R) {
-    case 12: return run_scan<12>(a, st);
-    case 3: return run_scan<3>(a, st);
-    default: return FFSR_EINVAL;
+  a.pairs = pairs;
+  for (int kb = 0; kb < 4; kb += pairs ? 2 : 4) {      // pairs: the directions {0, 1}, then {2, 3} on top of them (stream order)
+    a.kbase = kb;
+    a.nk = pairs ? 2 : 4;
+    int rc;
+    switch (R) {
+      case 12: rc = run_scan<12>(a, st); break;
+      case 3: rc = run_scan<3>(a, st); break;
+      default: return FFSR_EINVAL;
+    }
+    if (rc != FFSR_OK) return rc;
   }
+  return FFSR_OK;
+}
+}  // namespace
+
+extern "C" int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw,
+                                        const float* dtb, const float* A, const float* Dv, float* y, int ldy,
+                                        float* hstate, float* decay, int B, int H, int W, int Dm, int R, int d_state,
+                                        int chunk, void* stream) {
+  return scan_common(u, ldu, xdbl, ldx, dtw, dtb, A, Dv, y, ldy, hstate, decay, B, H, W, Dm, R, d_state, chunk, 0, stream);
 }
 
-extern "C" int ffsr_mamba_norm_gate_planes_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
-                                               const float* gamma, const float* beta, float eps, float* out, int ldo,
-                                               void* out_hi, void* out_lo, int ldp, int M, int C, void* stream) {
-  FFSR_CHECK(y && z && gamma && beta && (out || (out_hi && out_lo)) && M > 0 && C > 0 && C <= 512);
+// See include/ffsr.h.
+extern "C" int ffsr_selective_scan4_pairs_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw,
+                                              const float* dtb, const float* A, const float* Dv, float* y, int ldy,
+                                              float* hstate, float* decay, int B, int H, int W, int Dm, int R, int d_state,
+                                              int chunk, void* stream) {
+  return scan_common(u, ldu, xdbl, ldx, dtw, dtb, A, Dv, y, ldy, hstate, decay, B, H, W, Dm, R, d_state, chunk, 1, stream);
+}
+
+namespace {
+int norm_gate_common(const float* y, long long ystride, int ndir, int ldy, const float* z, int ldz, const float* gamma,
+                     const float* beta, float eps, float* out, int ldo, void* out_hi, void* out_lo, int ldp, int M, int C,
+                     void* stream) {
+  FFSR_CHECK(y && z && gamma && beta && (out || (out_hi && out_lo)) && M > 0 && C > 0 && C <= 512 && (ndir == 4 || ndir == 2));
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   FFSR_CHECK(!out_hi || (out_lo && (ldp & 31) == 0 && ldp >= C && ldp < C + 32 && al(out_hi) && al(out_lo)));
   const bool v8 = (C % 4 == 0) && (ldy % 4 == 0) && (ystride % 4 == 0) && (ldz % 4 == 0) && al(y) && al(z) && al(gamma) &&
                   al(beta) && (!out || (ldo % 4 == 0 && al(out)));
   hipStream_t st = (hipStream_t)stream;
   if (!v8) {
-    FFSR_CHECK(out && !out_hi);
+    FFSR_CHECK(out && !out_hi && ndir == 4);
     FFSR_LAUNCH(mamba_norm_gate_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz, gamma,
                        beta, eps, out, ldo, M, C);
     return ffsr_launch_status();
@@ -378,11 +414,25 @@ extern "C" int ffsr_mamba_norm_gate_planes_f32(const float* y, long long ystride
   unsigned short* ol = (unsigned short*)out_lo;
   if (C <= 256)
     FFSR_LAUNCH(mamba_norm_gate_v8_kernel<1>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
-                       gamma, beta, eps, out, ldo, oh, ol, ldp, M, C);
+                       gamma, beta, eps, out, ldo, oh, ol, ldp, M, C, ndir);
   else
     FFSR_LAUNCH(mamba_norm_gate_v8_kernel<2>, dim3((M + 7) / 8), dim3(256), 0, st, y, (size_t)ystride, ldy, z, ldz,
-                       gamma, beta, eps, out, ldo, oh, ol, ldp, M, C);
+                       gamma, beta, eps, out, ldo, oh, ol, ldp, M, C, ndir);
   return ffsr_launch_status();
+}
+}  // namespace
+
+extern "C" int ffsr_mamba_norm_gate_planes_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
+                                               const float* gamma, const float* beta, float eps, float* out, int ldo,
+                                               void* out_hi, void* out_lo, int ldp, int M, int C, void* stream) {
+  return norm_gate_common(y, ystride, 4, ldy, z, ldz, gamma, beta, eps, out, ldo, out_hi, out_lo, ldp, M, C, stream);
+}
+
+// See include/ffsr.h: the same over the TWO pair planes of ffsr_selective_scan4_pairs_f32.
+extern "C" int ffsr_mamba_norm_gate_pairs_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,
+                                              const float* gamma, const float* beta, float eps, float* out, int ldo,
+                                              void* out_hi, void* out_lo, int ldp, int M, int C, void* stream) {
+  return norm_gate_common(y, ystride, 2, ldy, z, ldz, gamma, beta, eps, out, ldo, out_hi, out_lo, ldp, M, C, stream);
 }
 
 extern "C" int ffsr_mamba_norm_gate_f32(const float* y, long long ystride, int ldy, const float* z, int ldz,

@@ -55,8 +55,10 @@ class _VSS:
         u = ops.dwconv2d(to_map(xz[:, :Dm], B, H, W), self.dw, act=ACT_SILU)  # [B,H,W,Dm]
         ut = tokens(u)
         xdbl = ops.linear(ut, self.x_proj)                                    # [P, 4*(R+32)]
-        y4 = ops.selective_scan4(ut, xdbl, self.dtw, self.dtb, self.A, self.Ds, B, H, W, Dm, self.R)
-        if pl and self.out_proj_t is not None and ops.tok_enabled() and ops.PROJ_FUSED:
+        fused_proj = pl and self.out_proj_t is not None and ops.tok_enabled() and ops.PROJ_FUSED
+        y4 = ops.selective_scan4(ut, xdbl, self.dtw, self.dtb, self.A, self.Ds, B, H, W, Dm, self.R,
+                                 pairs=False if fused_proj else None)
+        if fused_proj:
             # (4-wave workgroups: the 12-k-step rows need ~440 registers, two waves per SIMD would spill)
             ops_w, ops.TOK_WAVES = ops.TOK_WAVES, ops.TOK_WAVES or 4
             try:

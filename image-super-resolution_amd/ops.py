@@ -971,27 +971,38 @@ def scan_chunk(L: int, waves_per_chunk: int = 24) -> int:
     return c
 
 
-def selective_scan4(u, xdbl, dtw, dtb, A, Dv, B, H, W, Dm, R, chunk=None):
-    """u [B*L, Dm], xdbl [B*L, 4*(R+32)] -> y [4, B*L, Dm] (per-direction outputs in pixel order)."""
+# FFSR_SCAN_PAIRS=1: the scan folds its four per-direction outputs into two planes (directions 2 / 3 add to what 0 / 1 wrote).
+# Off by default: measured at 352 x 512 x 360 the consumer gains what the scan loses (norm_gate 330 -> 212 us, scan 1756 -> 1877 us:
+# two half-size launches per pass quantise worse over the 4096 resident waves, and the read-modify-write is not free)
+SCAN_PAIRS = os.environ.get("FFSR_SCAN_PAIRS", "0") == "1"
+
+
+def selective_scan4(u, xdbl, dtw, dtb, A, Dv, B, H, W, Dm, R, chunk=None, pairs=None):
+    """u [B*L, Dm], xdbl [B*L, 4*(R+32)] -> y [4, B*L, Dm] (per-direction outputs in pixel order), or with `pairs` y [2, B*L, Dm] =
+    (y0 + y2, y1 + y3): the second pair of directions is scanned after the first and adds to its planes."""
     L = H * W
-    chunk = chunk or scan_chunk(L, 4 * B * ((Dm + 63) // 64))
+    pairs = (SCAN_PAIRS and L >= 16384) if pairs is None else pairs
+    nk = 2 if pairs else 4
+    chunk = chunk or scan_chunk(L, nk * B * ((Dm + 63) // 64))
     nchunk = (L + chunk - 1) // chunk
-    y = torch.empty(4, B * L, Dm, device=u.device)
-    hstate = torch.empty(B, 4, nchunk, Dm, 16, device=u.device)
+    y = torch.empty(nk, B * L, Dm, device=u.device)
+    hstate = torch.empty(B, nk, nchunk, Dm, 16, device=u.device)
     decay = torch.empty_like(hstate)
-    hip.call("ffsr_selective_scan4_f32", _ptr(u), _mat(u)[3], _ptr(xdbl), _mat(xdbl)[3], _ptr(dtw), _ptr(dtb), _ptr(A),
+    hip.call("ffsr_selective_scan4_pairs_f32" if pairs else "ffsr_selective_scan4_f32", _ptr(u), _mat(u)[3], _ptr(xdbl), _mat(xdbl)[3], _ptr(dtw), _ptr(dtb), _ptr(A),
              _ptr(Dv), _ptr(y), Dm, _ptr(hstate), _ptr(decay), B, H, W, Dm, R, 16, chunk, _stream())
     return y
 
 
 def mamba_norm_gate(y4, z, gamma, beta, eps=1e-5, out=None, out_planes=None, want_f32=True):
-    """y4 [4, M, C], z [M, C] (row stride ldz) -> LayerNorm(sum_k y4[k]) * silu(z); out_planes as in layernorm()."""
-    _, M, C = y4.shape
+    """y4 [4, M, C] (or the [2, M, C] pair planes of selective_scan4), z [M, C] (row stride ldz) -> LayerNorm(sum_k y4[k]) * silu(z);
+    out_planes as in layernorm()."""
+    nd, M, C = y4.shape
+    assert nd in (2, 4)
     if out_planes is True:
         out_planes = Planes(1, 1, M, C, y4.device)
     if out is None and (want_f32 or out_planes is None):
         out = torch.empty(M, C, device=y4.device)
-    hip.call("ffsr_mamba_norm_gate_planes_f32", _ptr(y4), M * C, C, _ptr(z), _mat(z)[3], _ptr(gamma), _ptr(beta), float(eps),
+    hip.call("ffsr_mamba_norm_gate_planes_f32" if nd == 4 else "ffsr_mamba_norm_gate_pairs_f32", _ptr(y4), M * C, C, _ptr(z), _mat(z)[3], _ptr(gamma), _ptr(beta), float(eps),
              _ptr(out), 0 if out is None else _mat(out)[3], None if out_planes is None else _ptr(out_planes.hi),
              None if out_planes is None else _ptr(out_planes.lo), 0 if out_planes is None else out_planes.Cp, M, C, _stream())
     if out_planes is not None:

@@ -283,9 +283,21 @@ int ffsr_pixel_mha_f32(const float* qkv, int ldq, float* out, int ldo, long long
 int ffsr_selective_scan4_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw, const float* dtb,
                              const float* A, const float* Dv, float* y, int ldy, float* hstate, float* decay, int B,
                              int H, int W, int Dm, int R, int d_state, int chunk, void* stream);
+/* The same scan with the four per-direction outputs folded into TWO planes: y [2][B, L, ldy]; the directions 0 and 1 are scanned
+ * first and write plane 0 / 1, then 2 and 3 are scanned and ADD their outputs to plane 0 / 1 (two half-size launches of each pass
+ * in stream order; the scan is ALU-bound, the read-modify-write rides in its memory slack).  Halves what the consumer
+ * (ffsr_mamba_norm_gate_pairs_f32) has to read back.  hstate / decay: scratch [B, 2, ceil(L/chunk), Dm, 16] each. */
+int ffsr_selective_scan4_pairs_f32(const float* u, int ldu, const float* xdbl, int ldx, const float* dtw, const float* dtb,
+                                   const float* A, const float* Dv, float* y, int ldy, float* hstate, float* decay, int B,
+                                   int H, int W, int Dm, int R, int d_state, int chunk, void* stream);
 /* out = LayerNorm(y0 + y1 + y2 + y3) * silu(z): mambair_arch.py:380-384.  ystride = elements between directions. */
 int ffsr_mamba_norm_gate_f32(const float* y, long long ystride, int ldy, const float* z, int ldz, const float* gamma,
                              const float* beta, float eps, float* out, int ldo, int M, int C, void* stream);
+/* out / planes = LayerNorm(p0 + p1) * silu(z) over the two pair planes of ffsr_selective_scan4_pairs_f32 (p0 = y0 + y2,
+ * p1 = y1 + y3); arguments as ffsr_mamba_norm_gate_planes_f32. */
+int ffsr_mamba_norm_gate_pairs_f32(const float* y, long long ystride, int ldy, const float* z, int ldz, const float* gamma,
+                                   const float* beta, float eps, float* out, int ldo, void* out_hi, void* out_lo, int ldp,
+                                   int M, int C, void* stream);
 
 /* ffsr_mamba_norm_gate_f32 that can also (or only) emit the result as bf16 hi / lo planes [M, ldp] for the out_proj
  * GEMM (ffsr_conv2d_planes); out may be NULL when the planes are given. */

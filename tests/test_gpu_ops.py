@@ -282,11 +282,18 @@ def test_selective_scan(ops, H, W, Dm, R, chunk):
         return t if k % 2 == 0 else t.reshape(B, Dm, W, H).transpose(2, 3).reshape(B, Dm, L)
     want = torch.stack([unorder(y[:, k], k) for k in range(4)], 0).transpose(2, 3).reshape(4, B * L, Dm)
     got = ops.selective_scan4(u.reshape(B * L, Dm).to(DEV), xdbl.reshape(B * L, -1).to(DEV), dtw.to(DEV), dtb.to(DEV),
-                              A.to(DEV), Dv.to(DEV), B, H, W, Dm, R, chunk=chunk)
+                              A.to(DEV), Dv.to(DEV), B, H, W, Dm, R, chunk=chunk, pairs=False)
     close(got.cpu(), want, 5e-5, "selective scan")
     z, g, b = rnd(B * L, Dm, seed=7), rnd(Dm, seed=8), rnd(Dm, seed=9)
     gated = ops.mamba_norm_gate(got, z.to(DEV), g.to(DEV), b.to(DEV))
     close(gated.cpu(), F.layer_norm(want.sum(0), (Dm,), g, b) * F.silu(z), 5e-5, "norm gate")
+    # pair planes: the directions 2 / 3 are scanned after 0 / 1 and add to their planes
+    two = ops.selective_scan4(u.reshape(B * L, Dm).to(DEV), xdbl.reshape(B * L, -1).to(DEV), dtw.to(DEV), dtb.to(DEV),
+                              A.to(DEV), Dv.to(DEV), B, H, W, Dm, R, chunk=chunk, pairs=True)
+    assert tuple(two.shape) == (2, B * L, Dm)
+    close(two.cpu(), torch.stack([want[0] + want[2], want[1] + want[3]]), 1e-4, "selective scan, pair planes")
+    gated2 = ops.mamba_norm_gate(two, z.to(DEV), g.to(DEV), b.to(DEV))
+    close(gated2.cpu(), F.layer_norm(want.sum(0), (Dm,), g, b) * F.silu(z), 5e-5, "norm gate over pair planes")
 
 
 @pytest.mark.parametrize("h,w", [(64, 64), (35, 51)])
