@@ -719,7 +719,8 @@ __global__ __launch_bounds__(64) void grl_stripe_kernel(const float* __restrict_
 // drop_thr and scaled by keep_scale = 1 / (1 - p)  (nn.MultiheadAttention(dropout=0.1), large_kernel_attention.py:196,298)
 // --------------------------------------------------------------------------------------------------------------
 template <int T>
-__global__ void pixel_mha_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo, long long S,
+__global__ __launch_bounds__(256) void pixel_mha_kernel(   // (without the bound: 128 registers, the T = 9 rows spill)
+    const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo, long long S,
                                  int E, int heads, unsigned drop_thr, float keep_scale, unsigned long long seed) {
   constexpr int HD = 16;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -563,7 +563,8 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dout, int ldo, flo
 // Attention dropout (drop_thr > 0): the forward pass used P' = P * m, m[t, j] = keep ? 1 / (1 - p) : 0 regenerated here from the
 // same (seed, element index); then dP = (dO V^T) * m, dS = P (dP - sum P dP) and dv uses P'.
 template <int T>
-__global__ void pixel_mha_bwd_a_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int ldo,
+__global__ __launch_bounds__(RB, 2) void pixel_mha_bwd_a_kernel(   // (without the bound: 128 registers, 220 spilled at T = 9)
+    const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int ldo,
                                        float* __restrict__ dqkv, int lddq, float* __restrict__ scratch, long long S, int E, int heads,
                                        unsigned drop_thr, float keep_scale, unsigned long long seed) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

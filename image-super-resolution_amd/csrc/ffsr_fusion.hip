@@ -49,7 +49,8 @@ __global__ void selector_gates_kernel(const float* __restrict__ raw, int ldr, co
 
 // phase 4 tail.  t_lr = conv1x1(128->32)(lka_out) at LR (hoisted before the bilinear: both are linear);
 // mod = sigmoid(W2 gelu(bilinear(t_lr)) + b2); out = clamp(img * (1 + 0.2 (mod - 0.5)), 0, 1)
-__global__ void modulate_kernel(const float* __restrict__ t_lr, int ldt, const float* __restrict__ w2,
+__global__ __launch_bounds__(256) void modulate_kernel(   // (without the bound the compiler caps at 128 registers: 95 spilled)
+    const float* __restrict__ t_lr, int ldt, const float* __restrict__ w2,
                                 const float* __restrict__ b2, const float* __restrict__ img, int ldi, float* __restrict__ out,
                                 int ldo, int B, int h, int w, int Hh, int Wh, float sh, float sw) {
   __shared__ float W2[96], B2[3];

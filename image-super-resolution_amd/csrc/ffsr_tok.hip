@@ -718,6 +718,8 @@ int launch_tok_w(const TokArgs& a, int waves, hipStream_t st) {
   constexpr int D = (MODE == 2 || MODE == 3) ? (FMAX * 5 <= 140 ? 5 : (FMAX * 4 <= 148 ? 4 : 3)) : (FMAX * 4 <= 128 ? 4 : 3);
   // the next tile's rows are prefetched into registers where that fits the 256 registers of two waves per SIMD
   constexpr bool PF8 = KS0 > 0 ? (RX && KS0 <= 6 && KS1 <= 6) : (MODE == 2 || KS1 <= 8);
+  // (measured and dropped: 4-wave workgroups with a 3-slot ring, so that TWO workgroups share a CU and drift apart -- K = 180 MLP
+  //  254 -> 243 us, in_proj 234 -> 227 us, but the head kernels need > 256 registers per wave at 4 waves and fall to one workgroup)
   switch (waves) {
     case 4: return launch_tok<KS1, NT2, 4, D, MODE, RX, true, KS0>(a, st);
     case 8: return launch_tok<KS1, NT2, 8, D, MODE, RX, PF8, KS0>(a, st);
