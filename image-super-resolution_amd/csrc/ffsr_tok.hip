@@ -884,6 +884,7 @@ extern "C" int ffsr_tok_gemm_f32(const float* x, int ldx, const void* w1, const 
     case 8: return launch_tok_w<8, 2, 2, false>(a, waves, st);
     case 9: return launch_tok_w<9, 2, 2, false>(a, waves, st);
     case 10: return launch_tok_w<10, 2, 2, false>(a, waves, st);
+    case 12: return launch_tok_w<12, 2, 2, false>(a, waves, st);      // MambaIR x_proj: d_inner 360 -> 4 x (dt_rank + 2 d_state)
     default: return FFSR_EINVAL;
   }
 }

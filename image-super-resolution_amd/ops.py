@@ -517,7 +517,7 @@ class TokGemm:
     eps1: float
 
 
-TOK_GEMM_KS = (2, 4, 6, 7, 8, 9, 10)
+TOK_GEMM_KS = (2, 4, 6, 7, 8, 9, 10, 12)
 
 
 def tok_gemm_ok(K: int, N: int) -> bool:

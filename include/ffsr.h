@@ -156,7 +156,7 @@ int ffsr_tok_proj_f32(const float* x, long long xstride, int xdirs, int ldx, con
  * workgroups with the next tile's rows in flight, 3-term split-bf16 products), 32 output features per step, stored as they
  * are produced.  w1 = bf16 [ceil(N/32)][2][ceil(K/32)][2 planes][64][8] with the rows in the lane-column order, b1 = fp32
  * [ceil(N/32) * 32] in the same order (image-super-resolution_amd/ops.py::pack_tok_gemm).  act: none / GELU / ReLU / LeakyReLU.
- * K, N % 4 == 0; ceil(K/32) in {2, 4, 6, 7, 8, 9, 10}.  Replaces LayerNorm + nn.Linear pairs whose LayerNorm output has no
+ * K, N % 4 == 0; ceil(K/32) in {2, 4, 6, 7, 8, 9, 10, 12}.  Replaces LayerNorm + nn.Linear pairs whose LayerNorm output has no
  * other consumer: norm1 + qkv of the Swin blocks (drct_arch.py:385-388 + :166), ln_1 + in_proj of the VSS blocks
  * (mambair_arch.py:417 + :238), norm1 + conv1 of the NAFBlocks (nafnet_arch.py:113-115), and the dense-block 1x1 "adjust"
  * convolutions + LeakyReLU (drct_arch.py:292-301). */

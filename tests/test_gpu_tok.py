@@ -110,6 +110,7 @@ def test_gelu_fast_matches_erf_gelu():
 
 
 @pytest.mark.parametrize("K,N,M,ln,bias,act", [(180, 540, 1000, True, True, 0), (308, 924, 2051, True, True, 0), (180, 720, 4099, True, False, 0),
+                                               (360, 176, 2500, False, False, 0), (360, 176, 352 * 512 + 8, False, False, 0),
                                                (64, 128, 3333, True, True, 0), (128, 256, 700, True, True, 0), (244, 32, 1500, False, True, 3),
                                                (212, 636, 352 * 512 + 8, True, True, 0), (276, 180, 900, False, True, 1)])
 def test_tok_gemm_with_layernorm_prologue(K, N, M, ln, bias, act):
