@@ -119,7 +119,7 @@ def test_tok_gemm_with_layernorm_prologue(K, N, M, ln, bias, act):
     channel slice of the dense-concat buffer (drct_arch.py:292-301)."""
     ops = mod("ops")
     g = gen(K * N + M)
-    wide = torch.randn(M, 308, generator=g) * 1.5 + 0.2
+    wide = torch.randn(M, max(308, K + 24), generator=g) * 1.5 + 0.2
     x = wide[:, :K]
     w = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g) * 0.1 if bias else None
