@@ -43,7 +43,7 @@ WORKER = textwrap.dedent("""
     W.load_model_dir = lambda model_dir, templates, fill: {"fusion": {"a": torch.tensor([1., 2., 3.])}}
 
     class Engine:
-        def __init__(self, weights, device, scale=4):
+        def __init__(self, weights, device, scale=4, fusion_flags=None):
             log["engine_device"] = str(device)
             assert torch.equal(weights["fusion"]["a"].cpu(), torch.tensor([1., 2., 3.]))     # rank 0's values reached us
         def process_u8(self, img):
