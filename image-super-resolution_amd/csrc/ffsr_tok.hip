@@ -30,14 +30,24 @@
 namespace {
 
 // The wave's 16 rows, fp32, in operand order: lane (token l & 15, q = l >> 4) holds columns 32 s + 8 q + 4 h + 0..3.
-template <int KS1>
+// BF (branch-free): a column past K reads column 0 of the (always valid) row and is zeroed by a select -- a load under a bounds
+// branch is compiled as an exec-masked block of its own and waited for one at a time.  Measured: the single-GEMM kernels and the
+// plain chains gain 2-8 % (qkv 383 -> 376 us, NAFNet's gated half 403 -> 369 us); the head kernels, already at 256 registers, lose
+// what the freer load scheduling costs them in spills (NAFNet head 543 -> 604 us, DRCT 559 -> 580 us) and keep the branches.
+template <int KS1, bool BF = true>
 __device__ __forceinline__ void tok_load_rows(const float* xr, int K, int q, floatx4 (&xv)[KS1][2]) {
 #pragma unroll
   for (int s = 0; s < KS1; ++s)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int k = 32 * s + 8 * q + 4 * h;
-      xv[s][h] = (k < K) ? *reinterpret_cast<const floatx4*>(xr + k) : floatx4{0.f, 0.f, 0.f, 0.f};   // K % 4 == 0
+      const int k = 32 * s + 8 * q + 4 * h;     // K % 4 == 0
+      if constexpr (BF) {
+        const bool in = k < K;
+        const floatx4 v = *reinterpret_cast<const floatx4*>(xr + (in ? k : 0));
+        xv[s][h] = in ? v : floatx4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        xv[s][h] = (k < K) ? *reinterpret_cast<const floatx4*>(xr + k) : floatx4{0.f, 0.f, 0.f, 0.f};
+      }
     }
 }
 
@@ -234,7 +244,7 @@ __device__ __forceinline__ void tok_gate_prologue(const TokArgs& p, const float*
     for (int d = 0; d < 3; ++d) {
       asm volatile("" ::: "memory");
       floatx4 t[KS0][2];
-      tok_load_rows<KS0>(xr + (d == 0 ? 2 : d == 1 ? 1 : 3) * p.xstride, K, q, t);
+      tok_load_rows<KS0, false>(xr + (d == 0 ? 2 : d == 1 ? 1 : 3) * p.xstride, K, q, t);
 #pragma unroll
       for (int s = 0; s < KS0; ++s) { xv[s][0] += t[s][0]; xv[s][1] += t[s][1]; }
     }
@@ -276,13 +286,13 @@ __device__ __forceinline__ void tok_gate_prologue(const TokArgs& p, const float*
   }
   if (p.z) {
     floatx4 t[KS0][2];
-    tok_load_rows<KS0>(p.z + row * p.ldz, K, q, t);
+    tok_load_rows<KS0, false>(p.z + row * p.ldz, K, q, t);
 #pragma unroll
     for (int s = 0; s < KS0; ++s)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[s][h][c] *= t[s][h][c] / (1.0f + __expf(-t[s][h][c]));
+        for (int c = 0; c < 4; ++c) xv[s][h][c] *= t[s][h][c] * __builtin_amdgcn_rcpf(1.0f + __expf(-t[s][h][c]));   // (1 ulp rcp: no IEEE division sequence)
   }
 }
 
@@ -377,8 +387,11 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
     long long t_;
     bool o_;
     const size_t r_ = tile_row(blockIdx.x, t_, o_);
-    tok_load_rows<KSL>(p.x + r_ * p.ldx, KL, q, xv);
-    if constexpr (HPF) tok_load_rows<KS1>(p.hres + r_ * p.ldhr, p.hres ? p.K : 0, q, hr);
+    tok_load_rows<KSL, !HEAD>(p.x + r_ * p.ldx, KL, q, xv);
+    if constexpr (HPF) {
+      if (p.hres) tok_load_rows<KS1, false>(p.hres + r_ * p.ldhr, p.K, q, hr);
+      else tok_load_rows<KS1, false>(p.x + r_ * p.ldx, 0, q, hr);       // zeros
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bias stores (before the first barrier)
 
@@ -406,8 +419,11 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       long long t_;
       bool o_;
       const size_t r_ = tile_row(nt, t_, o_);
-      tok_load_rows<KSL>(p.x + r_ * p.ldx, KL, q, xv);
-      if constexpr (HPF) tok_load_rows<KS1>(p.hres + r_ * p.ldhr, p.hres ? p.K : 0, q, hr);
+      tok_load_rows<KSL, !HEAD>(p.x + r_ * p.ldx, KL, q, xv);
+      if constexpr (HPF) {
+        if (p.hres) tok_load_rows<KS1, false>(p.hres + r_ * p.ldhr, p.K, q, hr);
+        else tok_load_rows<KS1, false>(p.x + r_ * p.ldx, 0, q, hr);
+      }
     };
     if constexpr (!HEAD && PFETCH) fetch_next();
 
