@@ -41,6 +41,10 @@ __device__ __forceinline__ void tok_load_rows(const float* xr, int K, int q, flo
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = 32 * s + 8 * q + 4 * h;     // K % 4 == 0
+      if (KS1 > 4 && s < KS1 - 1) {   // (compile-time; KS1 = ceil(K / 32) is the launchers' contract: only the last step can be partial)
+        xv[s][h] = *reinterpret_cast<const floatx4*>(xr + k);
+        continue;
+      }
       if constexpr (BF) {
         const bool in = k < K;
         const floatx4 v = *reinterpret_cast<const floatx4*>(xr + (in ? k : 0));
@@ -102,8 +106,114 @@ __device__ __forceinline__ void tok_prepare(int K, bool ln, float eps, int q, co
 // Epilogue of a wave's 16 tokens: accumulator tile n of lane (token, q) holds columns 32 (n >> 1) + 8 q + 4 (n & 1) + 0..3
 // (the packed W2 row order), i.e. the same column groups the lane loaded of its input row.
 // XR2: the residual after the post-LN is the row xr the wave holds (a head's result), not a global read.
+// ALLIN: N is a multiple of 32 (no partial tile at all; selected at run time for the narrow NAFNet shapes, where half the tiles are
+// "the last pair").
+template <int NT2, bool XR2, bool ALLIN = false>
+__device__ __forceinline__ void tok_epilogue_body(const TokArgs& p, floatx4 (&acc)[NT2], const floatx4 (&xr)[NT2 / 2][2], long long tok,
+                                                  bool tok_ok, size_t row, int q) {
+  const int N = p.N;
+  // Every vector / row read below is UNCONDITIONAL per lane (a column past N reads column 0 and is zeroed afterwards; N % 4 == 0) and
+  // the loops sit INSIDE the wave-uniform pointer tests: a load under a lane-dependent bounds branch becomes an exec-masked block of
+  // its own whose result is waited for before the next block starts -- NT2 dependent round trips per tile instead of one.
+  // (the compiler barrier keeps these loads BELOW the GEMM loop: they depend on nothing the loop computes and would otherwise be
+  //  hoisted in front of it, 50-150 registers live across the whole tile)
+  if constexpr (NT2 > 8) asm volatile("" ::: "memory");      // (the narrow NAFNet shapes have the registers and lose 20 % behind it)
+  int cl[NT2];
+  bool in[NT2];
+#pragma unroll
+  for (int n = 0; n < NT2; ++n) {
+    // NT2 = 2 ceil(N / 32) (the launchers' choice): only the last tile PAIR can reach past N -- for the others `in` is a compile-time
+    // true and the column a constant offset from one per-lane base (no select, no address register of its own)
+    const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
+    in[n] = (ALLIN || n < NT2 - 2) ? true : col < N;
+    cl[n] = in[n] ? col : 0;
+  }
+  if (p.b2) {
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) acc[n] += *reinterpret_cast<const floatx4*>(p.b2 + cl[n]);
+  }
+  if (!p.res_is_x) {
+    if (p.cvec) {
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) acc[n] *= *reinterpret_cast<const floatx4*>(p.cvec + cl[n]) * p.cscale;
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) acc[n] *= p.cscale;
+    }
+    if (p.res) {
+      const float* rr = p.res + row * p.ldr;
+      if (p.rvec) {
+#pragma unroll
+        for (int n = 0; n < NT2; ++n)
+          acc[n] += *reinterpret_cast<const floatx4*>(rr + cl[n]) * (*reinterpret_cast<const floatx4*>(p.rvec + cl[n]) * p.rscale);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) acc[n] += *reinterpret_cast<const floatx4*>(rr + cl[n]) * p.rscale;
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NT2; ++n) {
+    if (!in[n]) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (p.out_pre_ln && tok_ok && in[n]) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + cl[n]) = acc[n];
+  }
+  if (p.g2) {       // LayerNorm over the N output columns of the token (two-pass), affine, second residual
+    float s1 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) s1 += (acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 / (float)N;
+    float s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      const bool in = 32 * (n >> 1) + 8 * q + 4 * (n & 1) < N;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = in ? acc[n][c] - mean : 0.f;
+        acc[n][c] = d;
+        s2 = fmaf(d, d, s2);
+      }
+    }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 / (float)N + p.eps2);
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      const floatx4 v = acc[n] * rstd * *reinterpret_cast<const floatx4*>(p.g2 + cl[n]) + *reinterpret_cast<const floatx4*>(p.be2 + cl[n]);
+      if (in[n]) acc[n] = v;        // (acc is 0 in the padding columns and stays 0)
+    }
+    if constexpr (XR2) {
+#pragma unroll
+      for (int n = 0; n < NT2; ++n)
+        if (in[n]) acc[n] += xr[n >> 1][n & 1];
+    } else if (p.res2) {
+      const float* rr = p.res2 + row * p.ldr2;
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) {
+        const floatx4 r = *reinterpret_cast<const floatx4*>(rr + cl[n]);
+        if (in[n]) acc[n] += r;
+      }
+    }
+  }
+  if (!tok_ok) return;
+#pragma unroll
+  for (int n = 0; n < NT2; ++n) {
+    const int col = 32 * (n >> 1) + 8 * q + 4 * (n & 1);
+    if (p.out && !p.out_pre_ln && in[n]) *reinterpret_cast<floatx4*>(p.out + (size_t)tok * p.ldo + col) = acc[n];
+    if (p.o_hi && (ALLIN || n < NT2 - 2 || col < p.ldp)) {      // columns N .. ldp-1 of the planes are written as zeros (acc is zero there; ldp >= N)
+      unsigned h0, h1, l0, l1;
+      split4(acc[n], h0, h1, l0, l1);
+      *reinterpret_cast<uintx2*>(p.o_hi + (size_t)tok * p.ldp + col) = uintx2{h0, h1};
+      *reinterpret_cast<uintx2*>(p.o_lo + (size_t)tok * p.ldp + col) = uintx2{l0, l1};
+    }
+  }
+}
+
+// The narrow shapes (NT2 <= 8: NAFNet's c = 64 / 128) keep the per-tile guarded form: measured 374 us against 444-461 us for the
+// batched form at 1408 x 2048 x 64 (a pure streaming pass whose two 16-column tile pairs are half "last pair").
 template <int NT2, bool XR2>
-__device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT2], const floatx4 (&xr)[NT2 / 2][2], long long tok,
+__device__ __forceinline__ void tok_epilogue_guarded(const TokArgs& p, floatx4 (&acc)[NT2], const floatx4 (&xr)[NT2 / 2][2], long long tok,
                                              bool tok_ok, size_t row, int q) {
   const int N = p.N;
 #pragma unroll
@@ -174,6 +284,13 @@ __device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT
   }
 }
 
+template <int NT2, bool XR2>
+__device__ __forceinline__ void tok_epilogue(const TokArgs& p, floatx4 (&acc)[NT2], const floatx4 (&xr)[NT2 / 2][2], long long tok,
+                                             bool tok_ok, size_t row, int q) {
+  if constexpr (NT2 <= 8) tok_epilogue_guarded<NT2, XR2>(p, acc, xr, tok, tok_ok, row, q);
+  else tok_epilogue_body<NT2, XR2, false>(p, acc, xr, tok, tok_ok, row, q);
+}
+
 // The head's result row (bias already added; tile (s, g) of lane (token, q) = columns 32 s + 8 q + 4 g + 0..3):
 //   hv = LN0?(hv) + hres + hres2 * hvec2[batch];  columns >= K stay zero (they are the k padding of the chain's first GEMM)
 // HPF: the hres rows were prefetched into hr together with the head's input rows (narrow shapes, where a second exposed load
@@ -211,26 +328,47 @@ __device__ __forceinline__ void tok_head_epilogue(const TokArgs& p, floatx4 (&hv
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int col = 32 * s + 8 * q + 4 * h;
-        if (col < N)
-          hv[s][h] = hv[s][h] * rstd * *reinterpret_cast<const floatx4*>(p.g0 + col) + *reinterpret_cast<const floatx4*>(p.be0 + col);
+        const bool in = s < KS1 - 1 ? true : col < N;
+        const int c0 = in ? col : 0;
+        const floatx4 v = hv[s][h] * rstd * *reinterpret_cast<const floatx4*>(p.g0 + c0) + *reinterpret_cast<const floatx4*>(p.be0 + c0);
+        if (in) hv[s][h] = v;
       }
   }
-  const float* v2 = p.hvec2 ? p.hvec2 + (row / (size_t)p.rows_per_batch) * N : nullptr;
+  // (unconditional loads with clamped columns inside the wave-uniform pointer tests, see tok_epilogue)
+  asm volatile("" ::: "memory");
+  if constexpr (HPF) {
 #pragma unroll
-  for (int s = 0; s < KS1; ++s)
+    for (int s = 0; s < KS1; ++s)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int col = 32 * s + 8 * q + 4 * h;
-      if (col < N) {
-        if constexpr (HPF) hv[s][h] += hr[s][h];
-        else if (p.hres) hv[s][h] += *reinterpret_cast<const floatx4*>(p.hres + row * p.ldhr + col);
-        if (p.hres2) {
-          floatx4 r = *reinterpret_cast<const floatx4*>(p.hres2 + row * p.ldhr2 + col);
-          if (v2) r *= *reinterpret_cast<const floatx4*>(v2 + col);
-          hv[s][h] += r;
-        }
+      for (int h = 0; h < 2; ++h)
+        if (s < KS1 - 1 || 32 * s + 8 * q + 4 * h < N) hv[s][h] += hr[s][h];
+  } else if (p.hres) {
+    const float* rr = p.hres + row * p.ldhr;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = 32 * s + 8 * q + 4 * h;
+        const bool in = s < KS1 - 1 ? true : col < N;       // (N > 32 (KS1 - 1): only the last step is partial)
+        const floatx4 r = *reinterpret_cast<const floatx4*>(rr + (in ? col : 0));
+        if (in) hv[s][h] += r;
       }
-    }
+  }
+  if (p.hres2) {
+    const float* rr = p.hres2 + row * p.ldhr2;
+    const float* v2 = p.hvec2 ? p.hvec2 + (row / (size_t)p.rows_per_batch) * N : nullptr;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = 32 * s + 8 * q + 4 * h;
+        const bool in = s < KS1 - 1 ? true : col < N;
+        const int c0 = in ? col : 0;
+        floatx4 r = *reinterpret_cast<const floatx4*>(rr + c0);
+        if (v2) r *= *reinterpret_cast<const floatx4*>(v2 + c0);
+        if (in) hv[s][h] += r;
+      }
+  }
 }
 
 // MODE 3's input row: the sum of the xdirs partial rows (order of mambair_arch.py:381), LayerNorm with affine, * silu(z).
@@ -390,7 +528,10 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
     tok_load_rows<KSL, !HEAD>(p.x + r_ * p.ldx, KL, q, xv);
     if constexpr (HPF) {
       if (p.hres) tok_load_rows<KS1, false>(p.hres + r_ * p.ldhr, p.K, q, hr);
-      else tok_load_rows<KS1, false>(p.x + r_ * p.ldx, 0, q, hr);       // zeros
+      else {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) hr[s][0] = hr[s][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bias stores (before the first barrier)
@@ -422,7 +563,10 @@ __global__ __launch_bounds__(WAVES * 64) void tok_chain_kernel(TokArgs p) {
       tok_load_rows<KSL, !HEAD>(p.x + r_ * p.ldx, KL, q, xv);
       if constexpr (HPF) {
         if (p.hres) tok_load_rows<KS1, false>(p.hres + r_ * p.ldhr, p.K, q, hr);
-        else tok_load_rows<KS1, false>(p.x + r_ * p.ldx, 0, q, hr);
+        else {
+#pragma unroll
+          for (int s = 0; s < KS1; ++s) hr[s][0] = hr[s][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     };
     if constexpr (!HEAD && PFETCH) fetch_next();
