@@ -156,6 +156,22 @@ __device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&a
           for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
         }
       }
+      // The residual rows of this 32 x 32 tile are fetched HERE, before the transposition, unconditionally (row clamped to M - 1; an
+      // edge lane reads the row's first 8 columns and ignores them): under the per-row `m < M` / `fast` tests below each load was an
+      // exec-masked block of its own, waited for before the next one was issued.  tools/res_cost.py: + res cost 60-68 us per
+      // launch where the read itself is 26 us.  (Fetching a whole column tile's rows at once, 32 more live registers, slowed the
+      // kernel by 30 % WITHOUT a residual: keep it to the 16 of one tile.)
+      const bool res_pre = p.res && vec_ok && p.N >= 8;          // wave-uniform
+      floatx4 rv[2][2];
+      if (res_pre) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int m = min(m0 + wrow + im * 32 + pass * 16 + erow, p.M - 1);
+          const float* rp = p.res + (size_t)m * p.ldr + (fast ? nn : 0);
+          rv[pass][0] = *reinterpret_cast<const floatx4*>(rp);
+          rv[pass][1] = *reinterpret_cast<const floatx4*>(rp + 4);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r] = v[e] * cs_;
       // (the same wave wrote and reads T: LDS operations of one wave complete in order)
@@ -167,7 +183,10 @@ __device__ __forceinline__ void planes_epilogue(const PlaneArgs& p, floatx16 (&a
         const float* tp = T + row * 36 + ecol;
         if (fast) {
           floatx4 o0 = *reinterpret_cast<const floatx4*>(tp), o1 = *reinterpret_cast<const floatx4*>(tp + 4);
-          if (p.res) {
+          if (res_pre) {
+            o0 += rv[pass][0] * rs0;
+            o1 += rv[pass][1] * rs1;
+          } else if (p.res) {
             const float* rp = p.res + (size_t)m * p.ldr + nn;
             o0 += *reinterpret_cast<const floatx4*>(rp) * rs0;
             o1 += *reinterpret_cast<const floatx4*>(rp + 4) * rs1;
