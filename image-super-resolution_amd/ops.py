@@ -580,10 +580,11 @@ TOK_FUSED = os.environ.get("FFSR_TOK", "1") != "0"   # FFSR_TOK=0: LayerNorm / f
 
 
 HEAD_FUSED = os.environ.get("FFSR_TOK_HEAD", "1") != "0"   # FFSR_TOK_HEAD=0: attention proj (+ residual / LayerNorm) as own launches
-# FFSR_TOK_PROJ=1: MambaIR's out_norm + gate + out_proj + skip + ln_2 as ONE kernel (ffsr_tok_proj_f32).  Off by default: measured
-# 594 us (4-wave workgroups; 991 us with 8) against 591 us for the three launches it replaces -- its tiles are too short (5 us of MFMA
-# work per 64 tokens) to hide the load / store latencies of a workgroup that owns its CU alone (tools/proj_bench.py)
-PROJ_FUSED = os.environ.get("FFSR_TOK_PROJ", "0") == "1"
+# MambaIR's out_norm + gate + out_proj + skip + ln_2 as ONE kernel (ffsr_tok_proj_f32, 4-wave workgroups); FFSR_TOK_PROJ=0: the three
+# launches it replaces.  History of the measurement (tools/proj_bench.py, 352 x 512 x 360): first version 594 us against 591 us for
+# the three launches (its epilogue waited for every bias / LayerNorm-vector / residual load separately, one exec-masked block per
+# tile); with the batched epilogue loads 492 us against 556 us.
+PROJ_FUSED = os.environ.get("FFSR_TOK_PROJ", "1") != "0"
 
 
 def tok_enabled() -> bool:
