@@ -9,6 +9,8 @@ being rebuilt on the CPU and copied per image (grl_arch.py:431-453).
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import torch
@@ -49,12 +51,18 @@ def _cpb_bias_T(sd, p, table, index, device):
     return dev(b.permute(2, 1, 0), device), dev(logit, device)
 
 
+QKV_TOK = os.environ.get("FFSR_GRL_QKV_TOK", "1") != "0"
+
+
 class _Block:
     def __init__(self, sd, p, device, dim, heads, window_shift):
         self.dim, self.heads, self.hd = dim, heads, dim // 2 // heads
         self.shift = WS // 2 if window_shift else 0
         a = p + "attn."
         self.qkv = ops.pack_conv(sd[a + "qkv.body.weight"], sd[a + "qkv.body.bias"], device)
+        # qkv on the token GEMM (rows in registers, no LayerNorm: GRL is post-norm) instead of the planes tile kernel
+        self.qkv_t = ops.pack_tok_gemm(sd[a + "qkv.body.weight"], sd[a + "qkv.body.bias"], device) \
+            if QKV_TOK and ops.tok_gemm_ok(dim, 3 * dim) else None
         self.anchor = ops.pack_conv(sd[a + "anchor.body.0.reduction.weight"], sd[a + "anchor.body.0.reduction.bias"], device)
         self.proj = ops.pack_conv(sd[a + "proj.weight"], sd[a + "proj.bias"], device)
         AW = WS // DF
@@ -82,7 +90,10 @@ class _Block:
         C, hd, heads = self.dim, self.hd, self.heads
         pl = ops.PLANES_AUTO and ops.GEMM_MODE == "bf16x3"
         xm = to_map(x, B, H, W)
-        qkv = ops.linear(xp if xp is not None else x, self.qkv)            # [P, 3C]: window half | stripe half
+        if self.qkv_t is not None and ops.tok_enabled():
+            qkv = ops.tok_gemm(x, self.qkv_t)                              # [P, 3C]: window half | stripe half
+        else:
+            qkv = ops.linear(xp if xp is not None else x, self.qkv)
         anchor = ops.conv2d(ops.avgpool2(xm), self.anchor)                # [B, H/2, W/2, C/2]
         cat = torch.empty(x.shape[0], C, device=x.device)
         ops.grl_window_attn(qkv, 0, self.bw, self.lw, cat, 0, B, H, W, heads, hd, self.shift)
