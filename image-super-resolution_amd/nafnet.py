@@ -7,10 +7,15 @@ reference's forward hook captures, expert_loader.py:553-558).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
 from .common import dev, to_map, tokens
+
+
+CONV1_TOK_MAXC = int(os.environ.get("FFSR_NAF_CONV1_TOK_MAXC", "256"))   # norm1 + conv1 on the token GEMM up to this width
 
 
 class _Block:
@@ -35,7 +40,11 @@ class _Block:
         # first half: norm1 + conv1 as one kernel (nafnet_arch.py:113-115)
         self.conv1_t = ops.pack_tok_gemm(sd[p + "conv1.weight"], sd[p + "conv1.bias"], device,
                                          ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"]), eps=1e-6) \
-            if (c <= 128 and ops.tok_gemm_ok(c, 2 * c)) else None
+            if (c <= CONV1_TOK_MAXC and ops.tok_gemm_ok(c, 2 * c)) else None
+        # norm2 + conv4 likewise where the gated half is not one kernel (c = 256: LayerNorm 61 us + tile GEMM 237 us -> 204 us)
+        self.conv4_t = ops.pack_tok_gemm(sd[p + "conv4.weight"], sd[p + "conv4.bias"], device,
+                                         ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]), eps=1e-6) \
+            if (128 < c <= CONV1_TOK_MAXC and ops.tok_gemm_ok(c, 2 * c)) else None
         self.ffn = None
         if ops.tok_chain_ok(c, c, 1):
             gam = sd[p + "gamma"].detach().float().reshape(-1)
@@ -77,6 +86,10 @@ class _Block:
         if self.ffn is not None and ops.tok_enabled() and B * H * W > 64 * 24:
             yt = tokens(y)
             return to_map(ops.tok_chain(yt, self.ffn, res=yt), B, H, W)
+        if self.conv4_t is not None and ops.tok_enabled() and B * H * W > 64 * 24:
+            t = to_map(ops.tok_gemm(tokens(y), self.conv4_t), B, H, W)
+            g = ops.mul_add(t[..., :c], t[..., c:])              # SimpleGate
+            return ops.conv2d(g, self.conv5, res=y, cvec=self.gamma)
         t = ops.layernorm(y, *self.n2, eps=1e-6, out_planes=True if pl else None, want_f32=not pl)
         if self.conv4g is not None and ops.GEMM_MODE == "bf16x3" and ops.GATE_FUSED and B * H * W > 64 * 24:
             g = ops.conv2d(t, self.conv4g, gate=True)            # conv4 + SimpleGate in one kernel
