@@ -981,6 +981,7 @@ int tok_chain_common(const float* x, int ldx, const void* w1, const float* b1, c
   if (ks1 == KS && nt2 == NT && mode == MD)                                             \
     return a.res_is_x ? launch_tok_w<KS, NT, MD, true>(a, waves, st) : launch_tok_w<KS, NT, MD, false>(a, waves, st)
   // Swin / GRL MLPs (K = N = 180 .. 308)
+  FFSR_TOK_CASE(4, 8, 0);      // the fusion network's collaborative FFN (128 -> 256 -> 128 over 4 expert tokens per pixel)
   FFSR_TOK_CASE(6, 12, 0);
   FFSR_TOK_CASE(7, 14, 0);
   FFSR_TOK_CASE(8, 16, 0);

@@ -64,14 +64,23 @@ class _LKABlock:
 class _MHA:
     """nn.MultiheadAttention (eval) as in_proj GEMM -> per-pixel attention kernel -> out_proj GEMM (+ residual)."""
 
-    def __init__(self, sd, p, device, heads):
+    def __init__(self, sd, p, device, heads, ln=None):
+        """ln = (gamma, beta) of the LayerNorm in front of the attention: folded into in_proj's token GEMM (one launch)"""
         self.heads = heads
         self.inp = ops.pack_conv(sd[p + "in_proj_weight"], sd[p + "in_proj_bias"], device)
+        E = sd[p + "in_proj_weight"].shape[1]
+        self.inp_t = ops.pack_tok_gemm(sd[p + "in_proj_weight"], sd[p + "in_proj_bias"], device, ln=ln) \
+            if ln is not None and ops.tok_gemm_ok(E, 3 * E) else None
+        self.ln_fused = self.inp_t is not None
         self.out = ops.pack_conv(sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], device)
         self.E = self.out.N
 
     def __call__(self, normed, resid, S, T):
-        qkv = ops.linear(normed, self.inp)
+        """normed: the LayerNorm-ed tokens -- or, with `ln_fused`, the raw tokens (the norm rides in the in_proj kernel)"""
+        if self.inp_t is not None and self.ln_fused and ops.tok_enabled():
+            qkv = ops.tok_gemm(normed, self.inp_t)
+        else:
+            qkv = ops.linear(normed, self.inp)
         a = ops.pixel_mha(qkv, S, T, self.E, self.heads)
         return ops.linear(a, self.out, res=resid)
 
@@ -123,7 +132,7 @@ class FusionNet:
         p = "cross_band."
         self.band_proj = ops.pack_conv(sd[p + "band_proj.weight"], sd[p + "band_proj.bias"], device, cin_pad=4)
         self.cb_norm = (dev(g(p + "norm.weight"), device), dev(g(p + "norm.bias"), device))
-        self.cb_mha = _MHA(sd, p + "band_attention.", device, 4)
+        self.cb_mha = _MHA(sd, p + "band_attention.", device, 4, ln=(sd[p + "norm.weight"], sd[p + "norm.bias"]))
         self.cb_lka = _LKABlock(sd, p + "lka_block.", device)
         self.cb_out = ops.pack_conv(sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], device)
 
@@ -132,7 +141,11 @@ class FusionNet:
         p = "collaborative."
         self.align = {n: ops.pack_conv(sd[f"{p}align_layers.{n}.weight"], sd[f"{p}align_layers.{n}.bias"], device)
                       for n in EXPERTS}
-        self.co_mha = _MHA(sd, p + "cross_attn.", device, 8)
+        self.co_mha = _MHA(sd, p + "cross_attn.", device, 8, ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+        # norm2 + ffn + residual as one kernel (the Swin Mlp form: x + fc2(GELU(fc1(LayerNorm(x)))))
+        self.co_ffn = ops.pack_tok_chain(sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"], sd[p + "ffn.2.weight"], sd[p + "ffn.2.bias"],
+                                         device, mode=0, ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"])) \
+            if ops.tok_chain_ok(128, 128, 0) else None
         self.co_n1 = (dev(g(p + "norm1.weight"), device), dev(g(p + "norm1.bias"), device))
         self.co_n2 = (dev(g(p + "norm2.weight"), device), dev(g(p + "norm2.bias"), device))
         self.co_f0 = ops.pack_conv(sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"], device)
@@ -229,7 +242,8 @@ class FusionNet:
         P = B * h * w
         rows = bands.reshape(P * 9, 4)
         proj = ops.linear(rows, self.band_proj)                                     # [P*9, 64]
-        attn = self.cb_mha(ops.layernorm(proj, *self.cb_norm), proj, P, 9)          # + residual
+        fused = self.cb_mha.ln_fused and ops.tok_enabled()
+        attn = self.cb_mha(proj if fused else ops.layernorm(proj, *self.cb_norm), proj, P, 9)          # + residual
         routing = None
         for i in range(3):
             feat = attn.as_strided((B, h, w, 64), (h * w * 576, w * 576, 576, 1), attn.storage_offset() + 64 * i)
@@ -246,9 +260,13 @@ class FusionNet:
         for e, n in enumerate(EXPERTS):
             view = st.as_strided((B, h, w, 128), (h * w * 512, w * 512, 512, 1), 128 * e)
             ops.conv2d(feats[n], self.align[n], out=view)
-        s1 = self.co_mha(ops.layernorm(st, *self.co_n1), st, P, 4)
-        hdn = ops.linear(ops.layernorm(s1, *self.co_n2), self.co_f0, act=ACT_GELU)
-        s2 = ops.linear(hdn, self.co_f2, res=s1)
+        fused = self.co_mha.ln_fused and ops.tok_enabled()
+        s1 = self.co_mha(st if fused else ops.layernorm(st, *self.co_n1), st, P, 4)
+        if self.co_ffn is not None and ops.tok_enabled():
+            s2 = ops.tok_chain(s1, self.co_ffn, res=s1)
+        else:
+            hdn = ops.linear(ops.layernorm(s1, *self.co_n2), self.co_f0, act=ACT_GELU)
+            s2 = ops.linear(hdn, self.co_f2, res=s1)
         for e, n in enumerate(EXPERTS):
             view = s2.as_strided((B, h, w, 128), (h * w * 512, w * 512, 512, 1), s2.storage_offset() + 128 * e)
             t_lr = ops.conv2d(self.co_lka(view), self.mod0[e])                      # 1x1 128->32 at LR

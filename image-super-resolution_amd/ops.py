@@ -431,7 +431,7 @@ class TokChain:
     eps1: float
 
 
-TOK_SHAPES = {0: ((6, 12), (7, 14), (8, 16), (9, 18), (10, 20)), 1: ((2, 4), (4, 8))}
+TOK_SHAPES = {0: ((4, 8), (6, 12), (7, 14), (8, 16), (9, 18), (10, 20)), 1: ((2, 4), (4, 8))}
 
 
 def tok_chain_ok(K: int, N: int, mode: int) -> bool:

@@ -94,7 +94,7 @@ int ffsr_conv2d_planes(const void* a_hi, const void* a_lo, int Cp, const void* w
  *   form mixed_attn_block_efficient.py:543-554 (x + norm2(mlp(x))), swin_v1_block.py Mlp.
  * mode 1 (G = 4): SimpleGate, h = (W1a x + b1a) * (W1b x + b1b), 32 gated features per step: NAFBlock's second half
  *   y + gamma * conv5(SimpleGate(conv4(norm2(y)))), nafnet_arch.py:125-131.
- * K, N % 4 == 0; supported (ceil(K/32), ceil(N/16)): (6,12) (7,14) (8,16) (9,18) (10,20) for mode 0, (2,4) (4,8) for mode 1.
+ * K, N % 4 == 0; supported (ceil(K/32), ceil(N/16)): (4,8) (6,12) (7,14) (8,16) (9,18) (10,20) for mode 0, (2,4) (4,8) for mode 1.
  * waves: 8, 11 or 12 waves of 16 tokens per workgroup (0 = 8). */
 int ffsr_tok_chain_f32(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
                        const float* cvec, const float* res, int ldr, const float* rvec, const float* g2,
