@@ -38,7 +38,7 @@ class _Swin:
         # ... and the attention's output projection + residual in front of it (drct_arch.py:400-404): x1 = x + proj(attn) only
         # ever exists in the kernel's registers
         self.proj_t = ops.pack_tok_gemm(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], device) \
-            if self.mlp is not None and ops.tok_gemm_ok(dim, dim) else None
+            if self.mlp is not None and ops.tok_gemm_ok(dim, dim) and ops.tok_head_ok(dim, 0) else None
 
     def __call__(self, x, B, H, W, tail=None):
         """x [P, dim] (row stride may be wider) -> [P, dim]; tail (see ops.tok_chain): the dense block's adjust convolution rides

@@ -82,7 +82,7 @@ class _Block:
         # ... with the attention's output projection, norm1 and the two residuals as its head (x + norm1(proj(attn)) + CAB(x) stays
         # in the kernel's registers): mixed_attn_block_efficient.py:536-554
         self.proj_t = ops.pack_tok_gemm(sd[a + "proj.weight"], sd[a + "proj.bias"], device) \
-            if self.mlp is not None and ops.tok_gemm_ok(dim, dim) else None
+            if self.mlp is not None and ops.tok_gemm_ok(dim, dim) and ops.tok_head_ok(dim, "post") else None
 
     def __call__(self, x, B, H, W, xp=None):
         """x [P, dim] contiguous tokens (xp: the same tensor as bf16 hi/lo planes, if the producer emitted them)

@@ -58,7 +58,7 @@ class _Block:
         self.conv3_t = None
         # (c = 128 only: at c = 64 the pass is pure streaming -- measured 854 us fused against 413 + 420 us for conv3 and the
         #  gated half as two launches at 1408 x 2048, and slower still at 1024 x 1024; at c = 128 546 against 629 us)
-        if self.ffn is not None and c == 128 and ops.tok_gemm_ok(c, c):
+        if self.ffn is not None and c == 128 and ops.tok_gemm_ok(c, c) and ops.tok_head_ok(c, 1):
             bet = sd[p + "beta"].detach().float().reshape(-1)
             w3 = sd[p + "conv3.weight"].detach().float().reshape(c, c)
             self.conv3_t = ops.pack_tok_gemm(w3 * bet[:, None].to(w3.device), sd[p + "conv3.bias"].detach().float() * bet.to(w3.device),

@@ -434,6 +434,15 @@ class TokChain:
 TOK_SHAPES = {0: ((4, 8), (6, 12), (7, 14), (8, 16), (9, 18), (10, 20)), 1: ((2, 4), (4, 8))}
 
 
+# k-step counts ffsr_tok_head_chain_f32 is instantiated for: mode 0 (x1 + mlp(norm(x1))), mode 1 (gated chain), "post" (mode 0 with
+# the post-LayerNorm form norm(mlp(x1)) + x1)
+TOK_HEAD_KS = {0: (6, 7, 8, 9, 10), 1: (2, 4), "post": (6,)}
+
+
+def tok_head_ok(K: int, mode) -> bool:
+    return K % 4 == 0 and (K + 31) // 32 in TOK_HEAD_KS[mode]
+
+
 def tok_chain_ok(K: int, N: int, mode: int) -> bool:
     return K % 4 == 0 and N % 4 == 0 and ((K + 31) // 32, (N + 31) // 32 * 2) in TOK_SHAPES[mode]
 
