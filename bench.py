@@ -71,9 +71,9 @@ def cpu_baseline(weights, naf_cfg=None, tiles=5, full=False):
            "sample": f"{tiles} x 64x64 LR tiles -> 256x256 ({mp:.3f} MP), 4 experts + fusion, {dt:.1f} s of CPU work after one warm-up tile; "
                      f"{cores} threads = the box's CPU share for one GPU ({os.cpu_count()} logical cores visible)",
            # the tile sample flatters the CPU (cache-resident maps): one real 340x510 oracle pass on the same 16-core share
-           # measured 292 s = 0.0095 MP/s (profiles/r03_cpu_baseline_at_metric_size.md; re-measure with --cpu-full)
-           "at_metric_size": {"value": 0.0095, "unit": "output MP/s", "seconds_per_image": 292.0, "measured": "round 2, GPU box, "
-                              "16 threads, tests/test_gpu_baseline_configs.py::test_full_size_340x510_vs_oracle", "live": False}}
+           # measured 263 s = 0.0105 MP/s (profiles/r03_cpu_baseline_at_metric_size.md; re-measure with --cpu-full)
+           "at_metric_size": {"value": 0.0105, "unit": "output MP/s", "seconds_per_image": 263.4, "measured": "round 3, GPU box, "
+                              "16 threads, python bench.py --cpu-full (one 510x340 image, no warm-up)", "live": False}}
     if full:
         lr = synth_lr(1234, H_LR, W_LR)
         with torch.no_grad():
