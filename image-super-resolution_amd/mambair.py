@@ -69,12 +69,9 @@ class _VSS:
                                  pairs=False if fused_proj else None)
         if fused_proj:
             # (4-wave workgroups: the 12-k-step rows need ~440 registers, two waves per SIMD would spill)
-            ops_w, ops.TOK_WAVES = ops.TOK_WAVES, ops.TOK_WAVES or 4
-            try:
-                y, n2 = ops.tok_proj(y4[0], self.out_proj_t, xdirs=4, xstride=y4.stride(0), z=xz[:, Dm:], pro_ln=self.out_norm,
-                                     res=x, rvec=self.skip1, post_ln=self.ln2, out_pre_ln=True, out_planes=True)
-            finally:
-                ops.TOK_WAVES = ops_w
+            y, n2 = ops.tok_proj(y4[0], self.out_proj_t, xdirs=4, xstride=y4.stride(0), z=xz[:, Dm:], pro_ln=self.out_norm,
+                                 res=x, rvec=self.skip1, post_ln=self.ln2, out_pre_ln=True, out_planes=True,
+                                 waves=ops.TOK_WAVES or 4)
             c2, att = self.cab(n2.reshape_map(B, H, W))
             return ops.scale_add(y, tokens(c2), avec=self.skip2, bvec=att, rows_per_batch=H * W)
         g = ops.mamba_norm_gate(y4, xz[:, Dm:], *self.out_norm, out_planes=True if pl else None, want_f32=not pl)

@@ -715,7 +715,7 @@ def tok_proj_ok(K: int, N: int) -> bool:
 
 
 def tok_proj(x2d, tg: TokGemm, *, xdirs=1, xstride=0, z=None, pro_ln=None, peps=1e-5, cvec=None, cscale=1.0, res=None, rvec=None,
-             rscale=1.0, post_ln=None, eps2=1e-5, out_pre_ln=False, out=None, out_planes=None, want_f32=True):
+             rscale=1.0, post_ln=None, eps2=1e-5, out_pre_ln=False, out=None, out_planes=None, want_f32=True, waves=None):
     """ffsr_tok_proj_f32: y = (W0 a + b0) * cvec * cscale + res * rvec * rscale with a = [sum of xdirs partial rows ->]
     [LayerNorm(pro_ln) ->] [* silu(z)]; post_ln: planes (and out unless out_pre_ln) receive LayerNorm(y).
     x2d [M, >= K] is the first partial input; the others lie xstride elements apart."""
@@ -736,7 +736,7 @@ def tok_proj(x2d, tg: TokGemm, *, xdirs=1, xstride=0, z=None, pro_ln=None, peps=
              _ptr(rvec), _ptr(g2), _ptr(be2), float(eps2), _ptr(out), 0 if out is None else out.stride(0), int(out_pre_ln),
              None if out_planes is None else _ptr(out_planes.hi), None if out_planes is None else _ptr(out_planes.lo),
              0 if out_planes is None else out_planes.Cp, M, tg.K, tg.N, float(cscale), float(rscale),
-             tok_waves(M, (tg.K + 31) // 32), _stream())
+             waves or tok_waves(M, (tg.K + 31) // 32), _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * tg.K * tg.N, (M, tg.N, tg.K, 1, 3),
